@@ -1,0 +1,227 @@
+"""ctypes front end of the CPU oracle (oracle/bialign_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, by __graft_entry__.smoke() and by
+the cpu_baseline leg of bench.py -- never by anything under bialign_amd/.
+
+Besides the C calls this module restates, in the plainest possible Python, how
+the reference turns sequences/structures/parameters into the two integer score
+functions mu1(i,j), mu2(k,l) (reference bialignment.pyx:340-440 and
+bialignment_nonpyx.py:33-58); the tests use it to cross-check the product's
+own host-side scoring code.
+"""
+import ctypes
+import math
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB = os.path.join(HERE, "libbialign_oracle.so")
+BLOSUM62_TSV = os.path.join(os.path.dirname(HERE), "bialign_amd", "data", "BLOSUM62.tsv")
+
+STATES = [(0, 1, 0, 1), (0, 1, 1, 0), (0, 1, 1, 1), (1, 0, 0, 1), (1, 0, 1, 0),
+          (1, 0, 1, 1), (1, 1, 0, 1), (1, 1, 1, 0), (1, 1, 1, 1)]
+
+_lib = None
+
+
+def build(force=False):
+    src = os.path.join(HERE, "bialign_oracle.c")
+    if force or not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(src):
+        subprocess.run(["gcc", "-O2", "-fPIC", "-std=c11", "-shared", "-o", LIB, src], check=True)
+    return LIB
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = ctypes.CDLL(LIB)
+        i32p = ctypes.POINTER(ctypes.c_int32)
+        u8p = ctypes.POINTER(ctypes.c_uint8)
+        ip = ctypes.POINTER(ctypes.c_int)
+        c_int = ctypes.c_int
+        _lib.bialign_oracle_layer_elems.restype = ctypes.c_int64
+        _lib.bialign_oracle_layer_elems.argtypes = [c_int] * 3
+        _lib.bialign_oracle_affine_fill.argtypes = [c_int] * 6 + [i32p, i32p, i32p, i32p]
+        _lib.bialign_oracle_affine_traceback.argtypes = [c_int] * 6 + [i32p, i32p, i32p, u8p, c_int, ip, ip]
+        _lib.bialign_oracle_linear_fill.argtypes = [c_int] * 5 + [i32p, i32p, i32p, i32p]
+        _lib.bialign_oracle_linear_traceback.argtypes = [c_int] * 5 + [i32p, i32p, i32p, u8p, c_int, ip]
+    return _lib
+
+
+def _p(a, t):
+    return a.ctypes.data_as(ctypes.POINTER(t))
+
+
+# --------------------------------------------------------------------------
+# score inputs (plain restatement)
+# --------------------------------------------------------------------------
+
+def read_simmatrix(name, scale=100):
+    """nonpyx:33-58; "BLOSUM62" is served from the repo's own data table."""
+    rows = {}
+    if name == "BLOSUM62":
+        with open(BLOSUM62_TSV) as fh:
+            lines = [ln.rstrip("\n").split("\t") for ln in fh if not ln.startswith("#")]
+        keys = lines[0][1:]
+        for ln in lines[1:]:
+            rows[ln[0]] = {k: scale * int(v) for k, v in zip(keys, ln[1:])}
+        return rows
+    keys = None
+    with open(name) as fh:
+        for idx, ln in enumerate(fh):
+            if keys and idx > len(keys):
+                break
+            tok = ln.split()
+            if tok[0] == "-":
+                keys = tok[1:]
+            else:
+                rows[tok[0]] = {k: scale * int(v) for k, v in zip(keys, tok[1:])}
+    return rows
+
+
+def rna_features(structure):
+    """pyx:366-392 for a fixed dot-bracket string: (up, down, unp), 1-based."""
+    n = len(structure)
+    bpm = np.zeros((n + 1, n + 1))
+    stack = []
+    for i, c in enumerate(structure):
+        if c == "(":
+            stack.append(i)
+        elif c == ")":
+            j = stack.pop()
+            bpm[i + 1, j + 1] = bpm[j + 1, i + 1] = 1.0
+        else:
+            bpm[i + 1, i + 1] = 1.0
+    up = [sum(bpm[i][j] for j in range(1, i - 1)) for i in range(n + 1)]
+    down = [sum(bpm[i][j] for j in range(i + 1, n + 1)) for i in range(n + 1)]
+    unp = [1.0 - up[i] - down[i] for i in range(n + 1)]
+    return up, down, unp
+
+
+def mu_tables(seqA, seqB, strA, strB, params):
+    """Dense (n+1)x(m+1) int32 tables of mu1(i,j), mu2(k,l); row/col 0 are 0."""
+    n, m = len(seqA), len(seqB)
+    mu1 = np.zeros((n + 1, m + 1), dtype=np.int32)
+    mu2 = np.zeros((n + 1, m + 1), dtype=np.int32)
+    sim = read_simmatrix(params["simmatrix"]) if params.get("simmatrix") else None
+    for i in range(1, n + 1):
+        for j in range(1, m + 1):
+            if sim:
+                mu1[i, j] = sim[seqA[i - 1]][seqB[j - 1]]
+            elif seqA[i - 1] == seqB[j - 1]:
+                mu1[i, j] = params["sequence_match_similarity"]
+            else:
+                mu1[i, j] = params["sequence_mismatch_similarity"]
+    sw = params["structure_weight"]
+    if params["type"] == "RNA":
+        fa, fb = rna_features(strA), rna_features(strB)
+        for k in range(1, n + 1):
+            for l in range(1, m + 1):
+                mu2[k, l] = int(sw * (math.sqrt(fa[0][k] * fb[0][l]) + math.sqrt(fa[1][k] * fb[1][l])
+                                      + math.sqrt(fa[2][k] * fb[2][l])))
+    else:
+        for k in range(1, n + 1):
+            for l in range(1, m + 1):
+                mu2[k, l] = sw if strA[k - 1] == strB[l - 1] else 0
+    return mu1, mu2
+
+
+# --------------------------------------------------------------------------
+# DP calls
+# --------------------------------------------------------------------------
+
+def affine_fill(n, m, s, beta, gamma, delta, mu1, mu2):
+    L = lib().bialign_oracle_layer_elems(n, m, s)
+    layers = np.empty(9 * L, dtype=np.int32)
+    score = ctypes.c_int32()
+    mu1 = np.ascontiguousarray(mu1, dtype=np.int32)
+    mu2 = np.ascontiguousarray(mu2, dtype=np.int32)
+    rc = lib().bialign_oracle_affine_fill(n, m, s, beta, gamma, delta, _p(mu1, ctypes.c_int32),
+                                          _p(mu2, ctypes.c_int32), _p(layers, ctypes.c_int32),
+                                          ctypes.byref(score))
+    if rc:
+        raise ValueError(f"oracle affine_fill rc={rc}")
+    W = 2 * s + 1
+    return score.value, layers.reshape(9, n + 1, m + 1, W, W)
+
+
+def affine_traceback(n, m, s, beta, gamma, delta, mu1, mu2, layers):
+    cap = 2 * (n + m) + 4
+    buf = np.zeros(cap, dtype=np.uint8)
+    ln, ok = ctypes.c_int(), ctypes.c_int()
+    mu1 = np.ascontiguousarray(mu1, dtype=np.int32)
+    mu2 = np.ascontiguousarray(mu2, dtype=np.int32)
+    layers = np.ascontiguousarray(layers, dtype=np.int32)
+    rc = lib().bialign_oracle_affine_traceback(n, m, s, beta, gamma, delta, _p(mu1, ctypes.c_int32),
+                                               _p(mu2, ctypes.c_int32), _p(layers, ctypes.c_int32),
+                                               _p(buf, ctypes.c_uint8), cap, ctypes.byref(ln),
+                                               ctypes.byref(ok))
+    if rc:
+        raise ValueError(f"oracle affine_traceback rc={rc}")
+    return buf[:ln.value].copy(), bool(ok.value)
+
+
+def linear_fill(n, m, s, gamma, delta, mu1, mu2):
+    L = lib().bialign_oracle_layer_elems(n, m, s)
+    layer = np.empty(L, dtype=np.int32)
+    score = ctypes.c_int32()
+    mu1 = np.ascontiguousarray(mu1, dtype=np.int32)
+    mu2 = np.ascontiguousarray(mu2, dtype=np.int32)
+    rc = lib().bialign_oracle_linear_fill(n, m, s, gamma, delta, _p(mu1, ctypes.c_int32),
+                                          _p(mu2, ctypes.c_int32), _p(layer, ctypes.c_int32),
+                                          ctypes.byref(score))
+    if rc:
+        raise ValueError(f"oracle linear_fill rc={rc}")
+    W = 2 * s + 1
+    return score.value, layer.reshape(1, n + 1, m + 1, W, W)
+
+
+def linear_traceback(n, m, s, gamma, delta, mu1, mu2, layer):
+    cap = 2 * (n + m) + 4
+    buf = np.zeros(cap, dtype=np.uint8)
+    ln = ctypes.c_int()
+    mu1 = np.ascontiguousarray(mu1, dtype=np.int32)
+    mu2 = np.ascontiguousarray(mu2, dtype=np.int32)
+    layer = np.ascontiguousarray(layer, dtype=np.int32)
+    rc = lib().bialign_oracle_linear_traceback(n, m, s, gamma, delta, _p(mu1, ctypes.c_int32),
+                                               _p(mu2, ctypes.c_int32), _p(layer, ctypes.c_int32),
+                                               _p(buf, ctypes.c_uint8), cap, ctypes.byref(ln))
+    if rc:
+        raise ValueError(f"oracle linear_traceback rc={rc}")
+    return buf[:ln.value].copy(), True
+
+
+def trace_to_lists(codes):
+    return [[(c >> 3) & 1, (c >> 2) & 1, (c >> 1) & 1, c & 1] for c in codes]
+
+
+def band_cells(n, m, s):
+    for i in range(n + 1):
+        for j in range(m + 1):
+            for k in range(max(0, i - s), min(n, i + s) + 1):
+                for l in range(max(0, j - s), min(m, j + s) + 1):
+                    yield (i, j, k, l)
+
+
+def band_values(layers, n, m, s):
+    """Layers -> per-layer lists over in-band cells in lexicographic order
+    (the layout of the ``layers`` entries in tests/golden/*.json)."""
+    idx = np.array([(i, j, k - i + s, l - j + s) for (i, j, k, l) in band_cells(n, m, s)])
+    return [layer[idx[:, 0], idx[:, 1], idx[:, 2], idx[:, 3]] for layer in layers]
+
+
+def solve(seqA, seqB, strA, strB, params, want_trace=True):
+    """Whole reference hot path on the CPU: fill (+ traceback)."""
+    n, m, s = len(seqA), len(seqB), params["max_shift"]
+    beta, gamma, delta = params["gap_opening_cost"], params["gap_cost"], params["shift_cost"]
+    mu1, mu2 = mu_tables(seqA, seqB, strA, strB, params)
+    if beta != 0:
+        score, layers = affine_fill(n, m, s, beta, gamma, delta, mu1, mu2)
+        trace, ok = affine_traceback(n, m, s, beta, gamma, delta, mu1, mu2, layers) if want_trace else (None, True)
+    else:
+        score, layers = linear_fill(n, m, s, gamma, delta, mu1, mu2)
+        trace, ok = linear_traceback(n, m, s, gamma, delta, mu1, mu2, layers) if want_trace else (None, True)
+    return dict(score=score, layers=layers, trace=trace, complete=ok)
