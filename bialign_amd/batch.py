@@ -1,0 +1,38 @@
+"""Batch front end: many independent (A, B) pairs under one parameter set.
+
+The reference aligns one pair per ``BiAligner`` (reference bialign.py:11); the
+engine is batch-first (a single pair is a batch of one).  ``make_batch`` turns
+molecule strings into the LOOKUP form the C ABI takes; ``shard`` splits a batch
+over the ranks of a one-process-per-GPU job.
+"""
+from .scoring import ScoreModel
+
+
+def encode_pairs(pairs, params):
+    """pairs: iterable of (seqA, seqB, strA, strB) -> (model, mols_a, mols_b)."""
+    pairs = list(pairs)
+    for sa, sb, ta, tb in pairs:
+        if len(sa) != len(ta) or len(sb) != len(tb):
+            raise ValueError("Provided structure and sequence must have the same length.")
+    model = ScoreModel(params,
+                       sequences=[p[0] for p in pairs] + [p[1] for p in pairs],
+                       structures=[p[2] for p in pairs] + [p[3] for p in pairs])
+    mols_a = [(model.encode_sequence(sa), model.encode_structure(ta)) for sa, _, ta, _ in pairs]
+    mols_b = [(model.encode_sequence(sb), model.encode_structure(tb)) for _, sb, _, tb in pairs]
+    return model, mols_a, mols_b
+
+
+def make_batch(pairs, params, engine=None, hbm_budget_bytes=0):
+    from .engine import Batch, default_engine  # loads the HIP library (no CPU fallback)
+    model, mols_a, mols_b = encode_pairs(pairs, params)
+    return Batch(engine or default_engine(), mols_a, mols_b, model.s1, model.s2,
+                 params["gap_opening_cost"], params["gap_cost"], params["shift_cost"],
+                 params["max_shift"], hbm_budget_bytes=hbm_budget_bytes)
+
+
+def shard(npairs, rank, world_size):
+    """Contiguous block of pair indices owned by ``rank`` (pairs are independent,
+    so sharding needs no data-path collective)."""
+    base, extra = divmod(npairs, world_size)
+    start = rank * base + min(rank, extra)
+    return range(start, start + base + (1 if rank < extra else 0))

@@ -1,0 +1,465 @@
+// bialign_capi.hip -- C ABI (include/bialign.h) over the gfx950 kernels.
+//
+// Host-side responsibilities: validate, lay the batch out in HBM, cut it into
+// HBM-budgeted chunks, launch fill + traceback per chunk on the engine's
+// stream, time the kernels with HIP events, hand results back.  No CPU compute
+// path exists here: if the device or a kernel is unavailable the call fails.
+#include "bialign_kernels.hpp"
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "../../include/bialign.h"
+
+using namespace bialign;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                 \
+  do {                                                                                \
+    hipError_t e_ = (expr);                                                           \
+    if (e_ != hipSuccess)                                                             \
+      return fail(BIALIGN_E_DEVICE, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                  __FILE__, __LINE__);                                                \
+  } while (0)
+
+template <typename T>
+struct DevBuf {
+  T* p = nullptr;
+  size_t n = 0;
+  ~DevBuf() { release(); }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    n = 0;
+  }
+  hipError_t alloc(size_t count) {
+    release();
+    n = count;
+    return hipMalloc(reinterpret_cast<void**>(&p), std::max<size_t>(count, 1) * sizeof(T));
+  }
+  hipError_t upload(const T* src, size_t count, hipStream_t s) {
+    hipError_t e = alloc(count);
+    if (e != hipSuccess || count == 0) return e;
+    return hipMemcpyAsync(p, src, count * sizeof(T), hipMemcpyHostToDevice, s);
+  }
+};
+
+// Sweep geometry of one pair (mirrors the kernel's Geo<S>): strips, period, steps.
+void sweep_geometry(int n, int m, int S, int* NS, int* P, int* G) {
+  const int W = 2 * S + 1, R = 64 / W, RR = R - 1;
+  *NS = (n + 1 + RR - 1) / RR;
+  *P = std::max(m + 2, 2 * (R - 1) + 8);
+  *G = (*NS - 1) * *P + m + 2 * (R - 1) + (W - 1) + 1;
+}
+
+int64_t cells_of(int n, int m, int s) {
+  auto K = [s](int x) {
+    int64_t t = 0;
+    for (int i = 0; i <= x; ++i) t += std::min(x, i + s) - std::max(0, i - s) + 1;
+    return t;
+  };
+  return K(n) * K(m);
+}
+
+}  // namespace
+
+struct bialign_engine {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+};
+
+struct bialign_batch {
+  bialign_engine* eng = nullptr;
+  bialign_params prm{};
+  int affine = 0, NL = 1, S = 0;
+  int npairs = 0;
+  std::vector<PairDesc> pairs;      // host mirror (layer_off valid for the pair's chunk)
+  std::vector<int32_t> order;       // chunk-by-chunk launch order
+  std::vector<int> chunk_begin;     // index into order, size nchunks+1
+  int64_t cells = 0, trace_bytes = 0, max_chunk_dwords = 0;
+  size_t lds_bytes = 0;
+  DevBuf<PairDesc> d_pairs;
+  DevBuf<int32_t> d_order, d_s1, d_s2, d_layers, d_scores, d_tlen, d_complete;
+  DevBuf<uint8_t> d_seq_a, d_cls_a, d_seq_b, d_cls_b, d_trace;
+  int k1 = 0, k2 = 0;
+  bialign_timing timing{};
+  bool ran = false, ran_trace = false;
+
+  DeviceBatch view() const {
+    DeviceBatch v{};
+    v.pairs = d_pairs.p;
+    v.order = d_order.p;
+    v.seq_a = d_seq_a.p; v.cls_a = d_cls_a.p; v.seq_b = d_seq_b.p; v.cls_b = d_cls_b.p;
+    v.s1 = d_s1.p; v.s2 = d_s2.p;
+    v.k1 = k1; v.k2 = k2;
+    v.beta = prm.gap_opening_cost; v.gamma = prm.gap_cost; v.delta = prm.shift_cost;
+    v.layers = d_layers.p;
+    v.scores = d_scores.p;
+    v.trace = d_trace.p;
+    v.trace_len = d_tlen.p;
+    v.complete = d_complete.p;
+    return v;
+  }
+};
+
+namespace {
+
+size_t lds_need(int S, int NL, int k1, int k2, int n, int m) {
+  const int W = 2 * S + 1, PADB = S + 1;
+  const size_t nv = (NL == 9 ? 20 : 4) * W;
+  const size_t npad = (n + 3) & ~3, mpad = (m + 2 * PADB + 3) & ~3;
+  return (nv * NCOL + (size_t)k1 * k1 + (size_t)k2 * k2) * 4 + 2 * npad + 2 * mpad;
+}
+
+template <int S>
+int launch_fill_affine(const bialign_batch* b, const DeviceBatch& v, int first, int count) {
+  DeviceBatch w = v;
+  w.order = v.order + first;
+  auto kern = fill_affine_kernel<S>;
+  if (b->lds_bytes > 64 * 1024)
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_bytes));
+  hipLaunchKernelGGL(kern, dim3(count), dim3(64), b->lds_bytes, b->eng->stream, w);
+  HIP_TRY(hipGetLastError());
+  return BIALIGN_OK;
+}
+
+template <int S>
+int launch_traceback_affine(const bialign_batch* b, const DeviceBatch& v, int first, int count,
+                            bool do_trace) {
+  DeviceBatch w = v;
+  w.order = v.order + first;
+  const int blocks = (count + 63) / 64;
+  if (do_trace)
+    hipLaunchKernelGGL((traceback_affine_kernel<S, true>), dim3(blocks), dim3(64), 0, b->eng->stream, w, count);
+  else
+    hipLaunchKernelGGL((traceback_affine_kernel<S, false>), dim3(blocks), dim3(64), 0, b->eng->stream, w, count);
+  HIP_TRY(hipGetLastError());
+  return BIALIGN_OK;
+}
+
+int launch_fill(const bialign_batch* b, const DeviceBatch& v, int first, int count) {
+  if (b->affine) {
+    switch (b->S) {
+      case 0: return launch_fill_affine<0>(b, v, first, count);
+      case 1: return launch_fill_affine<1>(b, v, first, count);
+      case 2: return launch_fill_affine<2>(b, v, first, count);
+      case 3: return launch_fill_affine<3>(b, v, first, count);
+    }
+  }
+  return fail(BIALIGN_E_UNSUPPORTED, "no fill kernel for affine=%d max_shift=%d", b->affine, b->S);
+}
+
+int launch_traceback(const bialign_batch* b, const DeviceBatch& v, int first, int count, bool do_trace) {
+  if (b->affine) {
+    switch (b->S) {
+      case 0: return launch_traceback_affine<0>(b, v, first, count, do_trace);
+      case 1: return launch_traceback_affine<1>(b, v, first, count, do_trace);
+      case 2: return launch_traceback_affine<2>(b, v, first, count, do_trace);
+      case 3: return launch_traceback_affine<3>(b, v, first, count, do_trace);
+    }
+  }
+  return fail(BIALIGN_E_UNSUPPORTED, "no traceback kernel for affine=%d max_shift=%d", b->affine, b->S);
+}
+
+template <int S, int NL>
+int launch_dump(const bialign_batch* b, const DeviceBatch& v, int pid, int32_t* d_out) {
+  hipLaunchKernelGGL((dump_layers_kernel<S, NL>), dim3(256), dim3(256), 0, b->eng->stream, v, pid, d_out);
+  HIP_TRY(hipGetLastError());
+  return BIALIGN_OK;
+}
+
+int launch_dump_any(const bialign_batch* b, const DeviceBatch& v, int pid, int32_t* d_out) {
+  if (b->affine) {
+    switch (b->S) {
+      case 0: return launch_dump<0, 9>(b, v, pid, d_out);
+      case 1: return launch_dump<1, 9>(b, v, pid, d_out);
+      case 2: return launch_dump<2, 9>(b, v, pid, d_out);
+      case 3: return launch_dump<3, 9>(b, v, pid, d_out);
+    }
+  }
+  return fail(BIALIGN_E_UNSUPPORTED, "no dump kernel for affine=%d max_shift=%d", b->affine, b->S);
+}
+
+}  // namespace
+
+extern "C" {
+
+int bialign_abi_version(void) { return BIALIGN_ABI_VERSION; }
+
+const char* bialign_last_error(void) { return g_err.c_str(); }
+
+int bialign_device_count(void) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) return fail(BIALIGN_E_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e));
+  return n;
+}
+
+int bialign_engine_create(int device, bialign_engine** out) {
+  if (!out) return fail(BIALIGN_E_INVALID, "out is NULL");
+  *out = nullptr;
+  int n = 0;
+  HIP_TRY(hipGetDeviceCount(&n));
+  if (device < 0 || device >= n) return fail(BIALIGN_E_INVALID, "device %d out of range (0..%d)", device, n - 1);
+  HIP_TRY(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, device));
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(BIALIGN_E_UNSUPPORTED, "device %d is %s; this engine is built for gfx950 only", device,
+                prop.gcnArchName);
+  auto* e = new bialign_engine();
+  e->device = device;
+  hipError_t err = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
+  for (int i = 0; i < 4 && err == hipSuccess; ++i) err = hipEventCreate(&e->ev[i]);
+  if (err != hipSuccess) {
+    bialign_engine_destroy(e);
+    return fail(BIALIGN_E_DEVICE, "engine setup: %s", hipGetErrorString(err));
+  }
+  *out = e;
+  return BIALIGN_OK;
+}
+
+void bialign_engine_destroy(bialign_engine* e) {
+  if (!e) return;
+  (void)hipSetDevice(e->device);
+  for (auto& ev : e->ev)
+    if (ev) (void)hipEventDestroy(ev);
+  if (e->stream) (void)hipStreamDestroy(e->stream);
+  delete e;
+}
+
+int bialign_batch_create(bialign_engine* eng, const bialign_params* prm, const bialign_scoring* sc,
+                         const bialign_pairs* pr, int64_t hbm_budget, bialign_batch** out) {
+  if (!eng || !prm || !sc || !pr || !out) return fail(BIALIGN_E_INVALID, "NULL argument");
+  *out = nullptr;
+  if (pr->npairs < 1) return fail(BIALIGN_E_INVALID, "npairs must be >= 1");
+  if (prm->max_shift < 0) return fail(BIALIGN_E_INVALID, "max_shift must be >= 0");
+  if (prm->max_shift > BIALIGN_MAX_SHIFT)
+    return fail(BIALIGN_E_UNSUPPORTED, "max_shift %d > %d is not instantiated in this build", prm->max_shift,
+                BIALIGN_MAX_SHIFT);
+  if (sc->k1 < 1 || sc->k1 > 256 || sc->k2 < 1 || sc->k2 > 256 || !sc->s1 || !sc->s2)
+    return fail(BIALIGN_E_INVALID, "scoring tables: k1,k2 must be 1..256 and tables non-NULL");
+  HIP_TRY(hipSetDevice(eng->device));
+
+  std::unique_ptr<bialign_batch> b(new bialign_batch());
+  b->eng = eng;
+  b->prm = *prm;
+  b->affine = prm->gap_opening_cost != 0;  // pyx:204-205
+  b->NL = b->affine ? 9 : 1;
+  b->S = prm->max_shift;
+  b->npairs = pr->npairs;
+  b->k1 = sc->k1;
+  b->k2 = sc->k2;
+  const int S = b->S, W = 2 * S + 1;
+
+  // int32 safety window: finite scores and the drift of "-infinity" cells must
+  // stay within 2^28 of where they start (kernels rely on it, see THRESH).
+  int64_t amax = 0;
+  for (int t = 0; t < sc->k1 * sc->k1; ++t) amax = std::max<int64_t>(amax, std::llabs((long long)sc->s1[t]));
+  int64_t bmax = 0;
+  for (int t = 0; t < sc->k2 * sc->k2; ++t) bmax = std::max<int64_t>(bmax, std::llabs((long long)sc->s2[t]));
+  const int64_t colmax = amax + bmax + 2 * (std::llabs((long long)prm->gap_cost) + std::llabs((long long)prm->gap_opening_cost)) +
+                         2 * std::llabs((long long)prm->shift_cost);
+
+  int64_t tot_a = 0, tot_b = 0;
+  b->pairs.resize(pr->npairs);
+  std::vector<int64_t> pair_dwords(pr->npairs);
+  for (int p = 0; p < pr->npairs; ++p) {
+    const int n = pr->len_a[p], m = pr->len_b[p];
+    if (n < 1 || m < 1)  // the reference raises IndexError on empty molecules (pyx:407)
+      return fail(BIALIGN_E_INVALID, "pair %d: empty molecule (n=%d, m=%d)", p, n, m);
+    if ((2 * ((int64_t)n + m) + 8) * colmax >= (1 << 28))
+      return fail(BIALIGN_E_RANGE, "pair %d: scores may leave the int32 safety window (n+m=%d, column bound %lld)", p,
+                  n + m, (long long)colmax);
+    PairDesc& d = b->pairs[p];
+    d.n = n;
+    d.m = m;
+    sweep_geometry(n, m, S, &d.NS, &d.P, &d.G);
+    d.trace_cap = 2 * (n + m) + 2;
+    d.seq_a = pr->off_a[p];
+    d.seq_b = pr->off_b[p];
+    d.trace_off = b->trace_bytes;
+    b->trace_bytes += d.trace_cap;
+    pair_dwords[p] = (int64_t)d.G * 64 * b->NL * W;
+    b->cells += cells_of(n, m, S);
+    tot_a = std::max<int64_t>(tot_a, pr->off_a[p] + n);
+    tot_b = std::max<int64_t>(tot_b, pr->off_b[p] + m);
+    b->lds_bytes = std::max(b->lds_bytes, lds_need(S, b->NL, sc->k1, sc->k2, n, m));
+  }
+  if (b->lds_bytes > 160 * 1024)
+    return fail(BIALIGN_E_UNSUPPORTED, "molecules too long for the LDS staging (%zu bytes needed)", b->lds_bytes);
+
+  // ---- chunking under the HBM budget; inside a chunk longest sweeps first
+  size_t free_b = 0, total_b = 0;
+  HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+  int64_t budget = hbm_budget > 0 ? hbm_budget : (int64_t)(free_b * 0.85);
+  budget = std::min<int64_t>(budget, (int64_t)(free_b * 0.95));
+  const int64_t budget_dw = budget / 4;
+  b->order.resize(pr->npairs);
+  std::iota(b->order.begin(), b->order.end(), 0);
+  b->chunk_begin.push_back(0);
+  int64_t used = 0;
+  for (int p = 0; p < pr->npairs; ++p) {
+    if (pair_dwords[p] > budget_dw)
+      return fail(BIALIGN_E_NOMEM, "pair %d needs %lld bytes of layers, budget is %lld", p,
+                  (long long)pair_dwords[p] * 4, (long long)budget);
+    if (used + pair_dwords[p] > budget_dw) {
+      b->chunk_begin.push_back(p);
+      used = 0;
+    }
+    b->pairs[p].layer_off = used;
+    used += pair_dwords[p];
+    b->max_chunk_dwords = std::max(b->max_chunk_dwords, used);
+  }
+  b->chunk_begin.push_back(pr->npairs);
+  for (size_t c = 0; c + 1 < b->chunk_begin.size(); ++c)
+    std::stable_sort(b->order.begin() + b->chunk_begin[c], b->order.begin() + b->chunk_begin[c + 1],
+                     [&](int x, int y) { return b->pairs[x].G > b->pairs[y].G; });
+
+  // ---- upload
+  hipStream_t st = eng->stream;
+  HIP_TRY(b->d_pairs.upload(b->pairs.data(), b->pairs.size(), st));
+  HIP_TRY(b->d_order.upload(b->order.data(), b->order.size(), st));
+  HIP_TRY(b->d_s1.upload(sc->s1, (size_t)sc->k1 * sc->k1, st));
+  HIP_TRY(b->d_s2.upload(sc->s2, (size_t)sc->k2 * sc->k2, st));
+  HIP_TRY(b->d_seq_a.upload(pr->seq_a, tot_a, st));
+  HIP_TRY(b->d_cls_a.upload(pr->cls_a, tot_a, st));
+  HIP_TRY(b->d_seq_b.upload(pr->seq_b, tot_b, st));
+  HIP_TRY(b->d_cls_b.upload(pr->cls_b, tot_b, st));
+  HIP_TRY(b->d_layers.alloc(b->max_chunk_dwords));
+  HIP_TRY(b->d_scores.alloc(pr->npairs));
+  HIP_TRY(b->d_tlen.alloc(pr->npairs));
+  HIP_TRY(b->d_complete.alloc(pr->npairs));
+  HIP_TRY(b->d_trace.alloc(b->trace_bytes));
+  HIP_TRY(hipMemsetAsync(b->d_tlen.p, 0, sizeof(int32_t) * pr->npairs, st));
+  HIP_TRY(hipMemsetAsync(b->d_complete.p, 0, sizeof(int32_t) * pr->npairs, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  *out = b.release();
+  return BIALIGN_OK;
+}
+
+void bialign_batch_destroy(bialign_batch* b) {
+  if (!b) return;
+  (void)hipSetDevice(b->eng->device);
+  delete b;
+}
+
+int bialign_batch_get_info(const bialign_batch* b, bialign_batch_info* info) {
+  if (!b || !info) return fail(BIALIGN_E_INVALID, "NULL argument");
+  info->npairs = b->npairs;
+  info->nchunks = (int)b->chunk_begin.size() - 1;
+  info->affine = b->affine;
+  info->max_shift = b->S;
+  info->cells = b->cells;
+  info->layer_bytes = b->cells * 4 * b->NL;
+  info->hbm_layer_bytes = b->max_chunk_dwords * 4;
+  info->trace_bytes = b->trace_bytes;
+  return BIALIGN_OK;
+}
+
+int bialign_batch_run(bialign_batch* b, uint32_t flags) {
+  if (!b) return fail(BIALIGN_E_INVALID, "NULL batch");
+  HIP_TRY(hipSetDevice(b->eng->device));
+  const bool do_trace = !(flags & BIALIGN_RUN_FILL_ONLY);
+  const DeviceBatch v = b->view();
+  hipStream_t st = b->eng->stream;
+  hipEvent_t* ev = b->eng->ev;
+  b->timing = bialign_timing{};
+  const int nchunks = (int)b->chunk_begin.size() - 1;
+  for (int c = 0; c < nchunks; ++c) {
+    const int first = b->chunk_begin[c], count = b->chunk_begin[c + 1] - first;
+    HIP_TRY(hipEventRecord(ev[0], st));
+    int rc = launch_fill(b, v, first, count);
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(ev[1], st));
+    rc = launch_traceback(b, v, first, count, do_trace);
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(ev[2], st));
+    HIP_TRY(hipEventSynchronize(ev[2]));
+    float f = 0, t = 0;
+    HIP_TRY(hipEventElapsedTime(&f, ev[0], ev[1]));
+    HIP_TRY(hipEventElapsedTime(&t, ev[1], ev[2]));
+    b->timing.fill_ms += f;
+    b->timing.traceback_ms += t;
+    b->timing.fill_launches += 1;
+    b->timing.traceback_launches += 1;
+  }
+  HIP_TRY(hipStreamSynchronize(st));
+  b->ran = true;
+  b->ran_trace = do_trace;
+  return BIALIGN_OK;
+}
+
+int bialign_batch_get_timing(const bialign_batch* b, bialign_timing* t) {
+  if (!b || !t) return fail(BIALIGN_E_INVALID, "NULL argument");
+  *t = b->timing;
+  return BIALIGN_OK;
+}
+
+int bialign_batch_get_scores(const bialign_batch* b, int32_t* scores) {
+  if (!b || !scores) return fail(BIALIGN_E_INVALID, "NULL argument");
+  if (!b->ran) return fail(BIALIGN_E_INVALID, "bialign_batch_run has not been called");
+  HIP_TRY(hipSetDevice(b->eng->device));
+  HIP_TRY(hipMemcpy(scores, b->d_scores.p, sizeof(int32_t) * b->npairs, hipMemcpyDeviceToHost));
+  return BIALIGN_OK;
+}
+
+int bialign_batch_get_traces(const bialign_batch* b, uint8_t* trace, int64_t* trace_off, int32_t* trace_len,
+                             int32_t* complete) {
+  if (!b || !trace || !trace_off || !trace_len || !complete) return fail(BIALIGN_E_INVALID, "NULL argument");
+  if (!b->ran || !b->ran_trace) return fail(BIALIGN_E_INVALID, "no traceback has been run on this batch");
+  HIP_TRY(hipSetDevice(b->eng->device));
+  HIP_TRY(hipMemcpy(trace, b->d_trace.p, b->trace_bytes, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(trace_len, b->d_tlen.p, sizeof(int32_t) * b->npairs, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(complete, b->d_complete.p, sizeof(int32_t) * b->npairs, hipMemcpyDeviceToHost));
+  for (int p = 0; p < b->npairs; ++p) trace_off[p] = b->pairs[p].trace_off;
+  return BIALIGN_OK;
+}
+
+int bialign_batch_dump_layers(bialign_batch* b, int32_t pair, int32_t* out) {
+  if (!b || !out) return fail(BIALIGN_E_INVALID, "NULL argument");
+  if (pair < 0 || pair >= b->npairs) return fail(BIALIGN_E_INVALID, "pair %d out of range", pair);
+  HIP_TRY(hipSetDevice(b->eng->device));
+  hipStream_t st = b->eng->stream;
+  // one-pair launch: order entry = pair; the pair keeps its chunk-relative layer_off
+  DevBuf<int32_t> d_one;
+  HIP_TRY(d_one.upload(&pair, 1, st));
+  DeviceBatch v = b->view();
+  v.order = d_one.p;
+  int rc = launch_fill(b, v, 0, 1);
+  if (rc) return rc;
+  const PairDesc& d = b->pairs[pair];
+  const int W = 2 * b->S + 1;
+  const size_t elems = (size_t)b->NL * (d.n + 1) * (d.m + 1) * W * W;
+  DevBuf<int32_t> d_out;
+  HIP_TRY(d_out.alloc(elems));
+  rc = launch_dump_any(b, v, pair, d_out.p);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(out, d_out.p, elems * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  b->ran = false;  // the resident chunk's layers were overwritten
+  return BIALIGN_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,542 @@
+// bialign_kernels.hpp -- device code of the BiAlign DP engine for gfx950 (MI355X).
+//
+// Mapping of the 4-D lattice onto a wavefront (see DESIGN.md for the derivation)
+// ------------------------------------------------------------------------------
+// Lattice point q = (i,j,k,l), band coordinates a = k-i, b = l-j in [-s,s],
+// W = 2s+1.  One 64-lane wave owns one pair.  Lane L = il*W + aa holds the
+// (row, a) pair  i = strip*RR + il - 1,  a = aa - s  for R = 64/W lane rows, of
+// which il = 0 is a *ghost* row (the last row of the previous strip, re-read
+// from HBM) and il = 1..R-1 are the RR real rows of the strip.  At global step
+// g the lane works on column  j = (g - 2*il - aa) mod P  and computes the W
+// lattice points b = -s..s of that (i,j,a): all nine affine states each.
+// With this skew every predecessor named by the reference's case generator
+// (pyx:255-296) was computed 1, 2 or 3 steps earlier by lane L-1, L-W+1, L-W or
+// by the lane itself.  Values cross lanes through a per-wave LDS exchange array
+// (written at the end of a step, read at the start of the next one); values
+// needed 2 or 3 steps later wait in registers.  Nothing crosses waves, so the
+// sweep needs no barrier.
+//
+// Algebra (bit-exact regrouping of the reference's 15 cases per state, SURVEY.md
+// section 7 / Appendix A).  Halves: Y=(0,1) X=(1,0) M=(1,1), state = 3*hU + hV
+// in the reference's layer order (pyx:61-65).
+//   open(h,T) = beta if T is a gap half and h != T else 0
+//   f_T(v)    = max_h( open(h,T) + v[h] )
+//   H2[U][V](p) = f_V( M[(U,.)][p] )     served to group 2, offset (0,0,V)
+//   H3[U][V](p) = f_U( M[(.,V)][p] )     served to group 3, offset (U,0,0)
+//   G [U][V](p) = f_U( H2[.][V](p) )     served to group 1, offset (U,V)
+//   M[(U,V)][q] = max( c1 + G[U][V](q-(U,V)), c2 + H2[U][V](q-(0,0,V)),
+//                      c3 + H3[U][V](q-(U,0,0)) )  over the guard-valid groups
+// Guard-invalid predecessors (pyx:133-141) carry the sentinel SENT, far below
+// any reachable value; a result still in the sentinel window means "no valid
+// case" and becomes exactly -2^30 (pyx:299-303).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace bialign {
+
+constexpr int32_t NEG = -(1 << 30);                 // reference -infinity
+constexpr int32_t SENT = -(1 << 30) - (1 << 29);    // "guard failed" marker
+constexpr int32_t THRESH = -(1 << 30) - (1 << 28);  // below: no valid case
+constexpr int NCOL = 65;                            // 64 lanes + 1 sentinel column
+typedef int v4i __attribute__((ext_vector_type(4)));
+
+struct PairDesc {
+  int32_t n, m;       // lengths of A, B
+  int32_t NS, P, G;   // strips, column period, total steps of the sweep
+  int32_t trace_cap;  // 2(n+m)+2
+  int64_t seq_a, seq_b;   // offsets into the code arrays
+  int64_t layer_off;      // dword offset of this pair's records in the chunk buffer
+  int64_t trace_off;      // byte offset in the trace buffer
+};
+
+struct DeviceBatch {
+  const PairDesc* pairs;
+  const int32_t* order;  // launch order (block -> pair id)
+  const uint8_t *seq_a, *cls_a, *seq_b, *cls_b;
+  const int32_t *s1, *s2;
+  int32_t k1, k2;
+  int32_t beta, gamma, delta;
+  int32_t* layers;      // chunk buffer
+  int32_t* scores;      // [npairs]
+  uint8_t* trace;       // trace buffer
+  int32_t* trace_len;   // [npairs]
+  int32_t* complete;    // [npairs]
+};
+
+template <int S>
+struct Geo {
+  static constexpr int W = 2 * S + 1;
+  static constexpr int R = 64 / W;       // lane rows per wave (incl. ghost row)
+  static constexpr int RR = R - 1;       // real lattice rows per strip
+  static constexpr int LIVE = R * W;     // lanes in use
+  static constexpr int MAXOFF = 2 * (R - 1) + (W - 1);
+  static constexpr int PADB = S + 1;     // guard bytes around B codes in LDS
+};
+
+// Record geometry: one record per step, ND dwords per lane, stored as NCH4
+// 16-byte chunks [chunk][lane][4] followed by a [lane][TAIL] tail, so that every
+// store instruction of the wave writes one contiguous 1 KiB (or 256/768 B) run.
+template <int S, int NL>
+struct Rec {
+  static constexpr int W = 2 * S + 1;
+  static constexpr int ND = NL * W;
+  static constexpr int NCH4 = ND / 4;
+  static constexpr int TAIL = ND % 4;
+  static constexpr int RECDW = 64 * ND;
+  __host__ __device__ static inline int64_t dword(int64_t g, int lane, int d) {
+    return d < 4 * NCH4 ? g * RECDW + (d >> 2) * 256 + lane * 4 + (d & 3)
+                        : g * RECDW + NCH4 * 256 + lane * TAIL + (d - 4 * NCH4);
+  }
+};
+
+// dword index of layer value (state st) of lattice point (i, j, aa, bb).
+template <int S, int NL>
+__host__ __device__ inline int64_t cell_dword(const PairDesc& pd, int i, int j, int aa, int bb,
+                                              int st) {
+  constexpr int W = 2 * S + 1, RR = Geo<S>::RR;
+  const int strip = i / RR, il = i - strip * RR + 1;
+  const int64_t g = (int64_t)strip * pd.P + j + 2 * il + aa;
+  return pd.layer_off + Rec<S, NL>::dword(g, il * W + aa, bb * NL + st);
+}
+
+__device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
+// f_T for the three target halves; arguments are the values for source half Y, X, M.
+__device__ __forceinline__ int fM(int y, int x, int m) { return imax(imax(y, x), m); }
+__device__ __forceinline__ int fX(int y, int x, int m, int beta) { return imax(x, beta + imax(y, m)); }
+__device__ __forceinline__ int fY(int y, int x, int m, int beta) { return imax(y, beta + imax(x, m)); }
+
+// ---------------------------------------------------------------------------
+// Affine fill (pyx:474-509).  One wave per pair.
+// ---------------------------------------------------------------------------
+template <int S>
+__global__ void __launch_bounds__(64) fill_affine_kernel(const DeviceBatch A) {
+  using G_ = Geo<S>;
+  using R_ = Rec<S, 9>;
+  constexpr int W = G_::W, R = G_::R, RR = G_::RR, PADB = G_::PADB;
+  constexpr int NV = 20 * W, ND = R_::ND, NCH4 = R_::NCH4, TAIL = R_::TAIL, RECDW = R_::RECDW;
+  extern __shared__ __align__(16) int32_t smem[];
+
+  const PairDesc pd = A.pairs[A.order[blockIdx.x]];
+  const int n = pd.n, m = pd.m, P = pd.P;
+  const int L = threadIdx.x;
+  const int il = L / W, aa = L - il * W;
+  const bool live = L < R * W;
+  const bool ghost = (il == 0);
+  const int beta = A.beta, gamma = A.gamma, delta = A.delta;
+  const int k1 = A.k1, k2 = A.k2;
+  const int gD = gamma + delta, gg = 2 * gamma, ggdd = 2 * gamma + 2 * delta, dd = 2 * delta;
+
+  // ---- LDS carve-up
+  int32_t* xch = smem;                    // [NV][NCOL] exchange array
+  int32_t* s1 = xch + NV * NCOL;          // [k1*k1]
+  int32_t* s2 = s1 + k1 * k1;             // [k2*k2]
+  const int npad = (n + 3) & ~3, mpad = (m + 2 * PADB + 3) & ~3;
+  uint8_t* sa = reinterpret_cast<uint8_t*>(s2 + k2 * k2);  // seq A codes, [i-1]
+  uint8_t* ca = sa + npad;                                  // cls A,       [k-1]
+  uint8_t* sb = ca + npad;                                  // seq B codes, [j-1+PADB]
+  uint8_t* cb = sb + mpad;                                  // cls B,       [l-1+PADB]
+
+  for (int t = L; t < NV * NCOL; t += 64) xch[t] = SENT;
+  for (int t = L; t < k1 * k1; t += 64) s1[t] = A.s1[t];
+  for (int t = L; t < k2 * k2; t += 64) s2[t] = A.s2[t];
+  for (int t = L; t < n; t += 64) {
+    sa[t] = A.seq_a[pd.seq_a + t];
+    ca[t] = A.cls_a[pd.seq_a + t];
+  }
+  for (int t = L; t < m + 2 * PADB; t += 64) {
+    const int src = t - PADB;
+    const bool ok = src >= 0 && src < m;
+    sb[t] = ok ? A.seq_b[pd.seq_b + src] : 0;
+    cb[t] = ok ? A.cls_b[pd.seq_b + src] : 0;
+  }
+  __syncthreads();
+
+  // ---- per-lane constants
+  const int colLW = (live && il >= 1) ? L - W : 64;                    // (i-1, a)
+  const int colLW1 = (live && il >= 1 && aa < W - 1) ? L - W + 1 : 64; // (i-1, a+1)
+  const int colL1 = (live && il >= 1 && aa > 0) ? L - 1 : 64;          // (i,   a-1)
+  const int GOFF = P - 2 * (R - 1);  // steps between a bottom row and its ghost copy
+  int32_t* const lay = A.layers + pd.layer_off;
+
+  // ---- per-lane sweep state
+  int jj = -(2 * il + aa);  // column of this step (< 0: not started)
+  int strip = 0;
+  int i = 0, s1row = 0, s2row = 0;
+  bool act_row = false;
+  auto set_row = [&](int st) {
+    i = st * RR + il - 1;
+    const int k = i + aa - S;
+    act_row = live && i >= 0 && i <= n && k >= 0 && k <= n;
+    s1row = (i >= 1 && i <= n) ? sa[i - 1] * k1 : 0;
+    s2row = (k >= 1 && k <= n) ? ca[k - 1] * k2 : 0;
+  };
+  set_row(0);
+
+  // delay lines (values read one step after production, used later)
+  int dA1[2][W], dA2[2][W];  // GMM, GMX from (i-1,a): used at age 3
+  int dAx[2][W];             // GXM, GXX from (i-1,a): age 2
+  int dB[4][W];              // GMY, H3M[0..2] from (i-1,a+1): age 2
+  int dC[2][W];              // GYM, GYX from (i,a-1): age 2
+  int selfv[4][W];           // GYY, H3Y[0..2] of this lane's previous column
+  int ghostM[ND];            // ghost row: the nine layers of its W points
+#pragma unroll
+  for (int bb = 0; bb < W; ++bb) {
+    dA1[0][bb] = dA1[1][bb] = dA2[0][bb] = dA2[1][bb] = SENT;
+    dAx[0][bb] = dAx[1][bb] = dC[0][bb] = dC[1][bb] = SENT;
+#pragma unroll
+    for (int x = 0; x < 4; ++x) dB[x][bb] = selfv[x][bb] = SENT;
+  }
+#pragma unroll
+  for (int d = 0; d < ND; ++d) ghostM[d] = SENT;
+
+  for (int g = 0; g < pd.G; ++g) {
+    // ---- 1. exchange reads: what the three source lanes published last step
+    int inA[W][4], inB[W][8], inC[W][8];
+#pragma unroll
+    for (int bb = 0; bb < W; ++bb) {
+#pragma unroll
+      for (int x = 0; x < 4; ++x) inA[bb][x] = xch[(bb * 20 + x) * NCOL + colLW];
+#pragma unroll
+      for (int x = 0; x < 8; ++x) inB[bb][x] = xch[(bb * 20 + 4 + x) * NCOL + colLW1];
+#pragma unroll
+      for (int x = 0; x < 8; ++x) inC[bb][x] = xch[(bb * 20 + 12 + x) * NCOL + colL1];
+    }
+
+    // ---- 2. score inputs of this column (pyx:260-261; LOOKUP form)
+    const int jc = min(max(jj, 0), m + 1);
+    const int mu1 = s1[s1row + sb[jc - 1 + PADB]];
+    int mu2[W];
+#pragma unroll
+    for (int bb = 0; bb < W; ++bb) mu2[bb] = s2[s2row + cb[jc + bb]];  // l-1+PADB = jc+bb
+
+    const bool tile_act = act_row && jj >= 0 && jj <= m;
+    const bool is_origin = tile_act && i == 0 && jj == 0 && aa == S;
+    const int c3M = mu1 + dd, c_Mg = mu1 + gD;
+
+    // ---- 3. the W lattice points of this (i, j, a)
+    int outv[ND];
+    int h2y[3] = {SENT, SENT, SENT};  // H2[U][Y] of point bb-1 (same step, same lane)
+#pragma unroll
+    for (int bb = 0; bb < W; ++bb) {
+      const int l = jj + bb - S;
+      const bool act = tile_act && l >= 0 && l <= m;
+      const int mu2v = mu2[bb];
+      const int c_MM = mu1 + mu2v, c_gM = mu2v + gD, c2M = mu2v + dd;
+
+      int T[9];
+#pragma unroll
+      for (int hU = 0; hU < 3; ++hU) {
+#pragma unroll
+        for (int hV = 0; hV < 3; ++hV) {
+          // group 1: offset (U,V)
+          int gin = SENT;
+          bool ok1 = true;
+          if (hU == 2 && hV == 2) gin = dA2[0][bb];
+          if (hU == 2 && hV == 1) { ok1 = bb + 1 < W; if (ok1) gin = dA2[1][bb + 1 < W ? bb + 1 : 0]; }
+          if (hU == 2 && hV == 0) gin = dB[0][bb];
+          if (hU == 1 && hV == 2) { ok1 = bb >= 1; if (ok1) gin = dAx[0][bb >= 1 ? bb - 1 : 0]; }
+          if (hU == 1 && hV == 1) gin = dAx[1][bb];
+          if (hU == 1 && hV == 0) { ok1 = bb >= 1; if (ok1) gin = inB[bb >= 1 ? bb - 1 : 0][1]; }
+          if (hU == 0 && hV == 2) gin = dC[0][bb];
+          if (hU == 0 && hV == 1) { ok1 = bb + 1 < W; if (ok1) gin = dC[1][bb + 1 < W ? bb + 1 : 0]; }
+          if (hU == 0 && hV == 0) gin = selfv[0][bb];
+          const int c1 = (hU == 2 && hV == 2) ? c_MM
+                         : (hU == 2)          ? c_Mg
+                         : (hV == 2)          ? c_gM
+                         : (hU == hV)         ? gg
+                                              : ggdd;
+          // group 2: offset (0,0,V)
+          int h2in = SENT;
+          bool ok2 = true;
+          if (hV == 2) { ok2 = bb >= 1; if (ok2) h2in = inC[bb >= 1 ? bb - 1 : 0][2 + hU]; }
+          if (hV == 1) h2in = inC[bb][5 + hU];
+          if (hV == 0) { ok2 = bb >= 1; if (ok2) h2in = h2y[hU]; }
+          const int c2 = (hV == 2) ? c2M : gD;
+          // group 3: offset (U,0,0)
+          int h3in = SENT;
+          bool ok3 = true;
+          if (hU == 2) { ok3 = bb + 1 < W; if (ok3) h3in = dB[1 + hV][bb + 1 < W ? bb + 1 : 0]; }
+          if (hU == 1) h3in = inB[bb][5 + hV];
+          if (hU == 0) { ok3 = bb + 1 < W; if (ok3) h3in = selfv[1 + hV][bb + 1 < W ? bb + 1 : 0]; }
+          const int c3 = (hU == 2) ? c3M : gD;
+
+          int t = SENT;
+          bool any = false;
+          if (ok1) { t = c1 + gin; any = true; }
+          if (ok2) { t = any ? imax(t, c2 + h2in) : c2 + h2in; any = true; }
+          if (ok3) { t = any ? imax(t, c3 + h3in) : c3 + h3in; any = true; }
+          T[3 * hU + hV] = t;
+        }
+      }
+
+      // finalise: ghost rows take the stored layers; "no valid case" -> -2^30
+      // (pyx:299-303); points outside the lattice carry the sentinel.
+      const int low = act ? NEG : SENT;
+      int M[9];
+#pragma unroll
+      for (int q = 0; q < 9; ++q) {
+        const int tv = ghost ? ghostM[bb * 9 + q] : T[q];
+        const bool bad = (tv < THRESH) | !act;
+        M[q] = bad ? low : tv;
+      }
+      if (bb == S) M[8] = is_origin ? 0 : M[8];  // pyx:483-485
+#pragma unroll
+      for (int q = 0; q < 9; ++q) outv[bb * 9 + q] = M[q];
+
+      // derived values for the successors
+      int H2[3][3], H3[3][3], Gd[3][3];
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+        H2[u][0] = fY(M[3 * u], M[3 * u + 1], M[3 * u + 2], beta);
+        H2[u][1] = fX(M[3 * u], M[3 * u + 1], M[3 * u + 2], beta);
+        H2[u][2] = fM(M[3 * u], M[3 * u + 1], M[3 * u + 2]);
+      }
+#pragma unroll
+      for (int v = 0; v < 3; ++v) {
+        H3[0][v] = fY(M[v], M[3 + v], M[6 + v], beta);
+        H3[1][v] = fX(M[v], M[3 + v], M[6 + v], beta);
+        H3[2][v] = fM(M[v], M[3 + v], M[6 + v]);
+        Gd[0][v] = fY(H2[0][v], H2[1][v], H2[2][v], beta);
+        Gd[1][v] = fX(H2[0][v], H2[1][v], H2[2][v], beta);
+        Gd[2][v] = fM(H2[0][v], H2[1][v], H2[2][v]);
+      }
+      // publish (all reads of this step were issued above, LDS keeps order)
+      int32_t* row = xch + (bb * 20) * NCOL + L;
+      row[0 * NCOL] = Gd[2][2];
+      row[1 * NCOL] = Gd[2][1];
+      row[2 * NCOL] = Gd[1][2];
+      row[3 * NCOL] = Gd[1][1];
+      row[4 * NCOL] = Gd[2][0];
+      row[5 * NCOL] = Gd[1][0];
+#pragma unroll
+      for (int v = 0; v < 3; ++v) {
+        row[(6 + v) * NCOL] = H3[2][v];
+        row[(9 + v) * NCOL] = H3[1][v];
+      }
+      row[12 * NCOL] = Gd[0][2];
+      row[13 * NCOL] = Gd[0][1];
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+        row[(14 + u) * NCOL] = H2[u][2];
+        row[(17 + u) * NCOL] = H2[u][1];
+      }
+      selfv[0][bb] = Gd[0][0];
+#pragma unroll
+      for (int v = 0; v < 3; ++v) selfv[1 + v][bb] = H3[0][v];
+#pragma unroll
+      for (int u = 0; u < 3; ++u) h2y[u] = H2[u][0];
+    }
+
+    // ---- 4. delay lines
+#pragma unroll
+    for (int bb = 0; bb < W; ++bb) {
+      dA2[0][bb] = dA1[0][bb];
+      dA2[1][bb] = dA1[1][bb];
+      dA1[0][bb] = inA[bb][0];
+      dA1[1][bb] = inA[bb][1];
+      dAx[0][bb] = inA[bb][2];
+      dAx[1][bb] = inA[bb][3];
+      dB[0][bb] = inB[bb][0];
+#pragma unroll
+      for (int v = 0; v < 3; ++v) dB[1 + v][bb] = inB[bb][2 + v];
+      dC[0][bb] = inC[bb][0];
+      dC[1][bb] = inC[bb][1];
+    }
+
+    // ---- 5. ghost row: fetch next step's layers (written GOFF steps ago by the
+    //         bottom row of the previous strip; issued before this step's stores)
+    if (ghost && live) {
+      int nj = jj + 1, nstrip = strip;
+      if (nj == P) { nj = 0; ++nstrip; }
+      if (nstrip >= 1 && nj >= 0 && nj <= m) {
+        const int32_t* src = lay + (int64_t)(g + 1 - GOFF) * RECDW;
+        const int sl = L + (R - 1) * W;
+#pragma unroll
+        for (int c = 0; c < NCH4; ++c) {
+          const v4i v = __builtin_nontemporal_load(reinterpret_cast<const v4i*>(src + c * 256 + sl * 4));
+          ghostM[4 * c] = v.x; ghostM[4 * c + 1] = v.y; ghostM[4 * c + 2] = v.z; ghostM[4 * c + 3] = v.w;
+        }
+#pragma unroll
+        for (int t = 0; t < TAIL; ++t)
+          ghostM[4 * NCH4 + t] = __builtin_nontemporal_load(src + NCH4 * 256 + sl * TAIL + t);
+      }
+    }
+
+    // ---- 6. coalesced layer stores (pyx:504: M[state][idx] = ...)
+    if (tile_act && !ghost) {
+      int32_t* dst = lay + (int64_t)g * RECDW;
+#pragma unroll
+      for (int c = 0; c < NCH4; ++c) {
+        v4i v;
+        v.x = outv[4 * c]; v.y = outv[4 * c + 1]; v.z = outv[4 * c + 2]; v.w = outv[4 * c + 3];
+        *reinterpret_cast<v4i*>(dst + c * 256 + L * 4) = v;
+      }
+#pragma unroll
+      for (int t = 0; t < TAIL; ++t) dst[NCH4 * 256 + L * TAIL + t] = outv[4 * NCH4 + t];
+    }
+
+    // ---- 7. advance
+    ++jj;
+    if (jj == P) {
+      jj = 0;
+      ++strip;
+      set_row(strip);
+    }
+  }
+}
+
+// |U0-V0| + |U1-V1| of a column / state given its two halves (pyx:97, 541-545)
+__device__ __forceinline__ int shift_of(int hU, int hV) {
+  return hU == hV ? 0 : ((hU == 2 || hV == 2) ? 1 : 2);
+}
+
+// ---------------------------------------------------------------------------
+// Affine traceback (pyx:535-586).  One thread per pair; every step issues the
+// up-to-15 candidate loads together, so a column costs one HBM round trip.
+// ---------------------------------------------------------------------------
+template <int S, bool DO_TRACE>
+__global__ void __launch_bounds__(64) traceback_affine_kernel(const DeviceBatch A, int npairs) {
+  const int slot = blockIdx.x * 64 + threadIdx.x;
+  if (slot >= npairs) return;
+  const int pid = A.order[slot];
+  const PairDesc pd = A.pairs[pid];
+  const int n = pd.n, m = pd.m;
+  const int beta = A.beta, gamma = A.gamma, delta = A.delta;
+  const int32_t* lay = A.layers;
+  const uint8_t* sa = A.seq_a + pd.seq_a;
+  const uint8_t* ca = A.cls_a + pd.seq_a;
+  const uint8_t* sb = A.seq_b + pd.seq_b;
+  const uint8_t* cb = A.cls_b + pd.seq_b;
+
+  // pyx:573-582: best end layer, first one with the least shift
+  int endv[9];
+#pragma unroll
+  for (int q = 0; q < 9; ++q) endv[q] = lay[cell_dword<S, 9>(pd, n, m, S, S, q)];
+  int best = endv[0];
+#pragma unroll
+  for (int q = 1; q < 9; ++q) best = imax(best, endv[q]);
+  A.scores[pid] = best;
+  if (!DO_TRACE) return;
+
+  int st = -1, stkey = 0;
+#pragma unroll
+  for (int q = 0; q < 9; ++q) {
+    const int sh = shift_of(q / 3, q % 3);
+    if (endv[q] == best && (st < 0 || sh < stkey)) { st = q; stkey = sh; }
+  }
+
+  uint8_t* out = A.trace + pd.trace_off;
+  int i = n, j = m, k = n, l = m, d0 = 0, d1 = 0, len = 0, complete = 0;
+  int cur = best;
+  while (true) {
+    if (i == 0 && j == 0 && k == 0 && l == 0 && st == 8) { complete = 1; break; }
+    const int hU = st / 3, hV = st - 3 * hU;
+    const int u0 = hU >= 1, u1 = hU != 1, v0 = hV >= 1, v1 = hV != 1;
+    const int mu1 = (i >= 1 && j >= 1) ? A.s1[sa[i - 1] * A.k1 + sb[j - 1]] : 0;
+    const int mu2 = (k >= 1 && l >= 1) ? A.s2[ca[k - 1] * A.k2 + cb[l - 1]] : 0;
+    const int valU = hU == 2 ? mu1 : gamma, valV = hV == 2 ? mu2 : gamma;
+
+    // candidate predecessors in the generator's order (pyx:275-296):
+    // cld = stored layer value of the predecessor, csc = score of the column
+    int cld[15], csc[15], csrc[15];
+    bool cok[15];
+    {  // group 1, offset (U,V)
+      const int pi = i - u0, pj = j - u1, pk = k - v0, pl = l - v1;
+      const bool ok = pi >= 0 && pj >= 0 && pk >= 0 && pl >= 0 && abs(pk - pi) <= S && abs(pl - pj) <= S;
+      const int base = delta * shift_of(hU, hV) + valU + valV;
+#pragma unroll
+      for (int ss = 0; ss < 9; ++ss) {
+        const int ra = ss / 3, rb = ss - 3 * (ss / 3);
+        cok[ss] = ok;
+        csrc[ss] = ss;
+        csc[ss] = base + ((hU != 2 && ra != hU) ? beta : 0) + ((hV != 2 && rb != hV) ? beta : 0);
+        cld[ss] = ok ? lay[cell_dword<S, 9>(pd, pi, pj, pk - pi + S, pl - pj + S, ss)] : 0;
+      }
+    }
+    {  // group 2, offset (0,0,V), sources (U,h) for h = M, X, Y
+      const int pk = k - v0, pl = l - v1;
+      const bool ok = pk >= 0 && pl >= 0 && abs(pk - i) <= S && abs(pl - j) <= S;
+      const int base = delta * (v0 + v1) + valV;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const int h = 2 - c, ss = 3 * hU + h;
+        cok[9 + c] = ok;
+        csrc[9 + c] = ss;
+        csc[9 + c] = base + ((hV != 2 && h != hV) ? beta : 0);
+        cld[9 + c] = ok ? lay[cell_dword<S, 9>(pd, i, j, pk - i + S, pl - j + S, ss)] : 0;
+      }
+    }
+    {  // group 3, offset (U,0,0), sources (h,V)
+      const int pi = i - u0, pj = j - u1;
+      const bool ok = pi >= 0 && pj >= 0 && abs(k - pi) <= S && abs(l - pj) <= S;
+      const int base = delta * (u0 + u1) + valU;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const int h = 2 - c, ss = 3 * h + hV;
+        cok[12 + c] = ok;
+        csrc[12 + c] = ss;
+        csc[12 + c] = base + ((hU != 2 && h != hU) ? beta : 0);
+        cld[12 + c] = ok ? lay[cell_dword<S, 9>(pd, pi, pj, k - pi + S, l - pj + S, ss)] : 0;
+      }
+    }
+    // pyx:554-565: keep cases reproducing the cell, pick the first one that
+    // minimises [|d0|+|d1|, |d1|] after adding the offset AND the source state
+    int pick = -1, key0 = 0, key1 = 0;
+#pragma unroll
+    for (int c = 0; c < 15; ++c) {
+      if (!cok[c] || cld[c] + csc[c] != cur) continue;
+      const int o0 = c < 12 ? (c < 9 ? u0 : 0) : u0, o1 = c < 12 ? (c < 9 ? u1 : 0) : u1;
+      const int o2 = c < 12 ? v0 : 0, o3 = c < 12 ? v1 : 0;
+      const int ra = csrc[c] / 3, rb = csrc[c] - 3 * ra;
+      const int r0 = ra >= 1, r1 = ra != 1, r2 = rb >= 1, r3 = rb != 1;
+      const int t0 = d0 + (o0 - o2) + (r0 - r2), t1 = d1 + (o1 - o3) + (r1 - r3);
+      const int ka = abs(t0) + abs(t1), kb = abs(t1);
+      if (pick < 0 || ka < key0 || (ka == key0 && kb < key1)) { pick = c; key0 = ka; key1 = kb; }
+    }
+    if (pick < 0) break;  // pyx:570-571 -> "incomplete traceback"
+    const int o0 = pick < 12 ? (pick < 9 ? u0 : 0) : u0, o1 = pick < 12 ? (pick < 9 ? u1 : 0) : u1;
+    const int o2 = pick < 12 ? v0 : 0, o3 = pick < 12 ? v1 : 0;
+    d0 += o0 - o2;  // pyx:566: only the offset moves the running shift
+    d1 += o1 - o3;
+    if (len < pd.trace_cap) out[len] = (uint8_t)(o0 * 8 + o1 * 4 + o2 * 2 + o3);
+    ++len;
+    i -= o0; j -= o1; k -= o2; l -= o3;
+    int nst = 0, ncur = 0;
+#pragma unroll
+    for (int c = 0; c < 15; ++c)
+      if (c == pick) { nst = csrc[c]; ncur = cld[c]; }
+    st = nst;
+    cur = ncur;
+  }
+  if (len > pd.trace_cap) len = pd.trace_cap;
+  for (int x = 0, y = len - 1; x < y; ++x, --y) {  // pyx:586 reversed
+    const uint8_t t = out[x];
+    out[x] = out[y];
+    out[y] = t;
+  }
+  A.trace_len[pid] = len;
+  A.complete[pid] = complete;
+}
+
+// ---------------------------------------------------------------------------
+// Layer dump in the reference layout (tests only).
+// ---------------------------------------------------------------------------
+template <int S, int NL>
+__global__ void dump_layers_kernel(const DeviceBatch A, int pid, int32_t* out) {
+  constexpr int W = 2 * S + 1;
+  const PairDesc pd = A.pairs[pid];
+  const int n = pd.n, m = pd.m;
+  const int64_t cells = (int64_t)(n + 1) * (m + 1) * W * W;
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < cells;
+       t += (int64_t)gridDim.x * blockDim.x) {
+    const int bb = t % W, aa = (t / W) % W;
+    const int j = (t / (W * W)) % (m + 1), i = t / ((int64_t)W * W * (m + 1));
+    const int k = i + aa - S, l = j + bb - S;
+    const bool ok = k >= 0 && k <= n && l >= 0 && l <= m;
+    for (int q = 0; q < NL; ++q)
+      out[q * cells + t] = ok ? A.layers[cell_dword<S, NL>(pd, i, j, aa, bb, q)] : 0;
+  }
+}
+
+}  // namespace bialign

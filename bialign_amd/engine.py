@@ -1,0 +1,145 @@
+"""Python face of the C ABI: Engine (device + stream) and Batch (pairs in HBM).
+
+Thin by design -- argument marshalling only.  All DP work happens in
+libbialign_hip.so on the GPU; nothing here computes alignments.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from ._lib import lib, check
+
+STATES = [(0, 1, 0, 1), (0, 1, 1, 0), (0, 1, 1, 1), (1, 0, 0, 1), (1, 0, 1, 0),
+          (1, 0, 1, 1), (1, 1, 0, 1), (1, 1, 1, 0), (1, 1, 1, 1)]  # pyx:61-65
+
+
+def device_count():
+    n = lib.bialign_device_count()
+    if n < 0:
+        check(n)
+    return n
+
+
+def _ptr(arr, ctype):
+    return arr.ctypes.data_as(ctypes.POINTER(ctype))
+
+
+class Engine:
+    """One HIP device + stream.  Single-owner, not thread-safe."""
+
+    def __init__(self, device=0):
+        self._h = ctypes.c_void_p()
+        check(lib.bialign_engine_create(int(device), ctypes.byref(self._h)))
+        self.device = int(device)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib.bialign_engine_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+
+_default_engines = {}
+
+
+def default_engine(device=0):
+    if device not in _default_engines:
+        _default_engines[device] = Engine(device)
+    return _default_engines[device]
+
+
+class Batch:
+    """A set of independent pairs sharing one parameter set, resident in HBM.
+
+    ``mols_a`` / ``mols_b``: lists of ``(seq_codes uint8[n], class_codes uint8[n])``.
+    ``s1`` / ``s2``: int32 score tables (k1 x k1, k2 x k2).
+    """
+
+    def __init__(self, engine, mols_a, mols_b, s1, s2, gap_opening_cost, gap_cost, shift_cost,
+                 max_shift, hbm_budget_bytes=0):
+        if len(mols_a) != len(mols_b) or not mols_a:
+            raise ValueError("need the same, non-zero number of A and B molecules")
+        self.engine = engine
+        self.npairs = len(mols_a)
+        self.len_a = np.array([len(x[0]) for x in mols_a], dtype=np.int32)
+        self.len_b = np.array([len(x[0]) for x in mols_b], dtype=np.int32)
+        self.max_shift = int(max_shift)
+        off_a = np.zeros(self.npairs, dtype=np.int64)
+        off_b = np.zeros(self.npairs, dtype=np.int64)
+        off_a[1:] = np.cumsum(self.len_a[:-1])
+        off_b[1:] = np.cumsum(self.len_b[:-1])
+        seq_a = np.ascontiguousarray(np.concatenate([np.asarray(x[0], dtype=np.uint8) for x in mols_a]))
+        cls_a = np.ascontiguousarray(np.concatenate([np.asarray(x[1], dtype=np.uint8) for x in mols_a]))
+        seq_b = np.ascontiguousarray(np.concatenate([np.asarray(x[0], dtype=np.uint8) for x in mols_b]))
+        cls_b = np.ascontiguousarray(np.concatenate([np.asarray(x[1], dtype=np.uint8) for x in mols_b]))
+        if len(seq_a) != len(cls_a) or len(seq_b) != len(cls_b):
+            raise ValueError("sequence and structure codes must have equal length")
+        s1 = np.ascontiguousarray(s1, dtype=np.int32)
+        s2 = np.ascontiguousarray(s2, dtype=np.int32)
+        if seq_a.size and (seq_a.max() >= s1.shape[0] or seq_b.max() >= s1.shape[0]):
+            raise ValueError("sequence code outside the S1 table")
+        if cls_a.size and (cls_a.max() >= s2.shape[0] or cls_b.max() >= s2.shape[0]):
+            raise ValueError("structure class outside the S2 table")
+        prm = _lib.Params(int(gap_opening_cost), int(gap_cost), int(shift_cost), int(max_shift))
+        sc = _lib.Scoring(s1.shape[0], _ptr(s1, ctypes.c_int32), s2.shape[0], _ptr(s2, ctypes.c_int32))
+        pr = _lib.Pairs(self.npairs, _ptr(self.len_a, ctypes.c_int32), _ptr(self.len_b, ctypes.c_int32),
+                        _ptr(off_a, ctypes.c_int64), _ptr(off_b, ctypes.c_int64),
+                        _ptr(seq_a, ctypes.c_uint8), _ptr(cls_a, ctypes.c_uint8),
+                        _ptr(seq_b, ctypes.c_uint8), _ptr(cls_b, ctypes.c_uint8))
+        self._h = ctypes.c_void_p()
+        check(lib.bialign_batch_create(engine._h, ctypes.byref(prm), ctypes.byref(sc), ctypes.byref(pr),
+                                       int(hbm_budget_bytes), ctypes.byref(self._h)))
+        info = _lib.BatchInfo()
+        check(lib.bialign_batch_get_info(self._h, ctypes.byref(info)))
+        self.info = {k: getattr(info, k) for k, _ in info._fields_}
+        self.affine = bool(info.affine)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib.bialign_batch_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    def run(self, fill_only=False):
+        check(lib.bialign_batch_run(self._h, _lib.RUN_FILL_ONLY if fill_only else 0))
+
+    def timing(self):
+        t = _lib.Timing()
+        check(lib.bialign_batch_get_timing(self._h, ctypes.byref(t)))
+        return dict(fill_ms=t.fill_ms, traceback_ms=t.traceback_ms,
+                    fill_launches=t.fill_launches, traceback_launches=t.traceback_launches)
+
+    def scores(self):
+        out = np.empty(self.npairs, dtype=np.int32)
+        check(lib.bialign_batch_get_scores(self._h, _ptr(out, ctypes.c_int32)))
+        return out
+
+    def traces(self):
+        """-> (list of uint8 arrays of column codes start->end, complete flags)."""
+        buf = np.empty(max(1, self.info["trace_bytes"]), dtype=np.uint8)
+        off = np.empty(self.npairs, dtype=np.int64)
+        ln = np.empty(self.npairs, dtype=np.int32)
+        ok = np.empty(self.npairs, dtype=np.int32)
+        check(lib.bialign_batch_get_traces(self._h, _ptr(buf, ctypes.c_uint8), _ptr(off, ctypes.c_int64),
+                                           _ptr(ln, ctypes.c_int32), _ptr(ok, ctypes.c_int32)))
+        return [buf[off[p]:off[p] + ln[p]].copy() for p in range(self.npairs)], ok.astype(bool)
+
+    def dump_layers(self, pair):
+        """Layers of one pair in the reference layout [layer][i][j][k-i+s][l-j+s]."""
+        n, m, w = int(self.len_a[pair]), int(self.len_b[pair]), 2 * self.max_shift + 1
+        nl = 9 if self.affine else 1
+        out = np.empty((nl, n + 1, m + 1, w, w), dtype=np.int32)
+        check(lib.bialign_batch_dump_layers(self._h, int(pair), _ptr(out, ctypes.c_int32)))
+        return out
+
+
+def trace_codes_to_columns(codes, as_tuples=False):
+    """Column codes -> the reference's trace entries (lists for the affine
+    recurrence, pyx:568; tuples for the non-affine one, pyx:526)."""
+    cols = [[(c >> 3) & 1, (c >> 2) & 1, (c >> 1) & 1, c & 1] for c in codes.tolist()]
+    return [tuple(c) for c in cols] if as_tuples else cols

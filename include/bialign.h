@@ -1,0 +1,146 @@
+/*
+ * bialign.h -- C ABI of libbialign_hip.so, the MI355X (gfx950) engine for the
+ * BiAlign hot path: 4-D shift-banded DP fill + traceback.
+ *
+ * The reference has no FFI; its boundary for this path is the method surface
+ * of `cdef class BiAligner` (reference src/bialignment.pyx:155).  Each entry
+ * point below names the reference code it replaces.  Everything is plain C:
+ * pointers + sizes, no C++/torch types, no exceptions across the boundary.
+ * Every function that can fail returns 0 on success and a negative
+ * BIALIGN_E_* code otherwise; bialign_last_error() then holds a message for
+ * the calling thread.
+ *
+ * Units of work.  A *pair* is one (A, B) molecule pair, i.e. one BiAligner
+ * instance of the reference (src/bialign.py:11).  A *batch* is a set of
+ * independent pairs sharing one parameter set; the reference runs a batch of
+ * one.  Pairs are given in LOOKUP form:
+ *     mu1(i,j) = s1[seq_a[i-1] * k1 + seq_b[j-1]]     (pyx:405-412, 435-436)
+ *     mu2(k,l) = s2[cls_a[k-1] * k2 + cls_b[l-1]]     (pyx:414-429, 438-440)
+ * with uint8 codes prepared by the host side (bialign_amd/scoring.py).
+ *
+ * The engine is GPU only.  There is no CPU fallback behind this ABI.
+ */
+#ifndef BIALIGN_H
+#define BIALIGN_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BIALIGN_ABI_VERSION 1
+
+#define BIALIGN_OK 0
+#define BIALIGN_E_INVALID (-1)     /* bad argument (message says which) */
+#define BIALIGN_E_UNSUPPORTED (-2) /* e.g. max_shift above BIALIGN_MAX_SHIFT */
+#define BIALIGN_E_DEVICE (-3)      /* HIP runtime error */
+#define BIALIGN_E_NOMEM (-4)       /* a single pair does not fit the HBM budget */
+#define BIALIGN_E_RANGE (-5)       /* scores could leave the int32 safety window */
+
+#define BIALIGN_MAX_SHIFT 3 /* kernels are instantiated for max_shift 0..3 */
+#define BIALIGN_NEG_INF (-(1 << 30)) /* the reference's -infinity, pyx:303,484 */
+
+/* run flags */
+#define BIALIGN_RUN_FILL_ONLY 1u /* optimize() without traceback() */
+
+typedef struct bialign_engine bialign_engine; /* one per (process, device) */
+typedef struct bialign_batch bialign_batch;   /* inputs resident in HBM */
+
+/* BiAligner parameters that reach the DP (pyx:186-188, 230, 259). */
+typedef struct bialign_params {
+  int32_t gap_opening_cost; /* beta; != 0 selects the affine recurrence (pyx:204-205, 444) */
+  int32_t gap_cost;         /* gamma */
+  int32_t shift_cost;       /* Delta */
+  int32_t max_shift;        /* s, 0..BIALIGN_MAX_SHIFT */
+} bialign_params;
+
+/* Score tables, row-major, values already scaled (nonpyx:33: x100). */
+typedef struct bialign_scoring {
+  int32_t k1;        /* sequence alphabet size, 1..256 */
+  const int32_t* s1; /* k1*k1 */
+  int32_t k2;        /* structure class count, 1..256 */
+  const int32_t* s2; /* k2*k2 */
+} bialign_scoring;
+
+/* Host-side description of the pairs; copied to HBM by bialign_batch_create. */
+typedef struct bialign_pairs {
+  int32_t npairs;
+  const int32_t* len_a; /* [npairs] n >= 1 */
+  const int32_t* len_b; /* [npairs] m >= 1 */
+  const int64_t* off_a; /* [npairs] start of pair p in seq_a / cls_a */
+  const int64_t* off_b; /* [npairs] start of pair p in seq_b / cls_b */
+  const uint8_t* seq_a; /* sequence codes of all A molecules, concatenated */
+  const uint8_t* cls_a; /* structure classes, same indexing as seq_a */
+  const uint8_t* seq_b;
+  const uint8_t* cls_b;
+} bialign_pairs;
+
+typedef struct bialign_batch_info {
+  int32_t npairs;
+  int32_t nchunks;        /* HBM-budgeted chunks the batch is processed in */
+  int32_t affine;         /* 1 = nine-layer affine recurrence, 0 = one layer */
+  int32_t max_shift;
+  int64_t cells;          /* in-band lattice points of all pairs (the unit of the metric) */
+  int64_t layer_bytes;    /* algorithmic bytes: 36 B (affine) or 4 B per cell */
+  int64_t hbm_layer_bytes;/* allocated size of the largest chunk's layer buffer */
+  int64_t trace_bytes;    /* capacity of the trace buffer, sum of 2(n+m)+2 */
+} bialign_batch_info;
+
+typedef struct bialign_timing {
+  double fill_ms;      /* HIP-event time of the fill kernels of the last run */
+  double traceback_ms; /* ... of the traceback (or score-only) kernels */
+  int32_t fill_launches;
+  int32_t traceback_launches;
+} bialign_timing;
+
+int bialign_abi_version(void);
+/* Number of visible HIP devices (<0 on error). */
+int bialign_device_count(void);
+const char* bialign_last_error(void);
+
+/* Engine: device selection + one HIP stream + event pool.
+ * Replaces nothing in the reference (it has no device); one engine plays the
+ * role of the Python process that owns a BiAligner. */
+int bialign_engine_create(int device, bialign_engine** out);
+void bialign_engine_destroy(bialign_engine* eng);
+
+/* Upload a batch and allocate its DP storage: BiAligner.__init__ (pyx:179-197)
+ * for the part that reaches the DP, plus AffineDPMatrices / SparseMatrix4D
+ * allocation (pyx:478, 452).  hbm_budget_bytes = 0 lets the engine use ~85 %
+ * of the free device memory; a smaller budget forces more chunks. */
+int bialign_batch_create(bialign_engine* eng, const bialign_params* params,
+                         const bialign_scoring* scoring, const bialign_pairs* pairs,
+                         int64_t hbm_budget_bytes, bialign_batch** out);
+void bialign_batch_destroy(bialign_batch* b);
+int bialign_batch_get_info(const bialign_batch* b, bialign_batch_info* info);
+
+/* BiAligner.optimize() (pyx:443-509) followed -- unless BIALIGN_RUN_FILL_ONLY --
+ * by BiAligner.traceback() (pyx:513-586), for every pair, chunk by chunk.
+ * Returns after the device work has completed. */
+int bialign_batch_run(bialign_batch* b, uint32_t flags);
+int bialign_batch_get_timing(const bialign_batch* b, bialign_timing* t);
+
+/* Optimal scores: the return value of optimize() (pyx:471, 509). */
+int bialign_batch_get_scores(const bialign_batch* b, int32_t* scores /* [npairs] */);
+
+/* Traces: the return value of traceback() (pyx:531, 586).  Pair p's columns are
+ * trace[trace_off[p] .. trace_off[p] + trace_len[p]), start -> end, one byte per
+ * column = o0*8 + o1*4 + o2*2 + o3.  complete[p] == 0 is the condition under
+ * which the reference prints "WARNING: incomplete traceback" (pyx:584-585);
+ * it is always 1 for the non-affine recurrence.  trace must hold
+ * bialign_batch_info.trace_bytes bytes. */
+int bialign_batch_get_traces(const bialign_batch* b, uint8_t* trace, int64_t* trace_off,
+                             int32_t* trace_len, int32_t* complete);
+
+/* Test / introspection hooks.
+ * dump_layers re-runs the fill of one pair and writes its layers in the
+ * reference's layout [layer][i][j][k-i+s][l-j+s] (pyx:27-41, 61-71), layers in
+ * itertools.product order, cells the reference never writes left 0.
+ * out must hold nlayers*(n+1)*(m+1)*(2s+1)^2 int32. */
+int bialign_batch_dump_layers(bialign_batch* b, int32_t pair, int32_t* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BIALIGN_H */

@@ -1,0 +1,105 @@
+"""GPU parity: the HIP engine (through the C ABI) against the CPU oracle and the
+golden vectors of the compiled reference.  Bit-exact: scores, traces, layers."""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from bialign_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+KNOWN = load_golden("known_answers.json")
+SMALL = load_golden("small_layers.json")
+MEDIUM = load_golden("medium_traces.json")
+
+
+def supported(rec):
+    from bialign_amd import _lib
+    return rec["params"]["max_shift"] <= _lib.MAX_SHIFT
+
+
+def gpu_solve(rec, layers=False):
+    from bialign_amd.batch import make_batch
+    from bialign_amd.engine import trace_codes_to_columns
+    b = make_batch([(rec["seqA"], rec["seqB"], rec["strA"], rec["strB"])], rec["params"])
+    b.run()
+    score = int(b.scores()[0])
+    traces, ok = b.traces()
+    out = dict(score=score, trace=trace_codes_to_columns(traces[0]), complete=bool(ok[0]))
+    if layers:
+        out["layers"] = b.dump_layers(0)
+    b.close()
+    return out
+
+
+def check_against_golden(rec):
+    from oracle import oracle
+    if not supported(rec):
+        pytest.skip("max_shift not instantiated")
+    want_layers = "layers" in rec
+    got = gpu_solve(rec, layers=want_layers)
+    assert got["score"] == rec["score"]
+    assert got["trace"] == rec["trace"]
+    assert got["complete"] == rec["complete"]
+    if want_layers:
+        n, m, s = len(rec["seqA"]), len(rec["seqB"]), rec["params"]["max_shift"]
+        vals = oracle.band_values(got["layers"], n, m, s)
+        for g, e in zip(vals, rec["layers"]):
+            np.testing.assert_array_equal(g, np.array(e, dtype=np.int64))
+
+
+@pytest.mark.parametrize("rec", KNOWN, ids=[r["name"] for r in KNOWN])
+def test_known_answers(rec):
+    check_against_golden(rec)
+
+
+@pytest.mark.parametrize("rec", SMALL, ids=[r["name"] for r in SMALL])
+def test_small_full_layers(rec):
+    check_against_golden(rec)
+
+
+@pytest.mark.parametrize("rec", MEDIUM, ids=[r["name"] for r in MEDIUM])
+def test_medium_traces(rec):
+    check_against_golden(rec)
+
+
+@pytest.mark.parametrize("n,m,s,seed", [(130, 75, 1, 5), (75, 130, 2, 6), (200, 200, 0, 7),
+                                         (61, 64, 3, 8), (257, 129, 1, 9)])
+def test_full_layers_vs_oracle(n, m, s, seed):
+    """Several strips / ragged shapes: every layer cell against the oracle."""
+    from oracle import oracle
+    sa, sb, ta, tb = synth.protein_pair(seed, n, m)
+    params = dict(synth.PROTEIN_PARAMS, max_shift=s)
+    rec = dict(seqA=sa, seqB=sb, strA=ta, strB=tb, params=params)
+    ref = oracle.solve(sa, sb, ta, tb, params)
+    got = gpu_solve(rec, layers=True)
+    assert got["score"] == ref["score"]
+    assert got["trace"] == oracle.trace_to_lists(ref["trace"])
+    assert got["complete"] == ref["complete"]
+    gv = oracle.band_values(got["layers"], n, m, s)
+    rv = oracle.band_values(ref["layers"], n, m, s)
+    for g, e in zip(gv, rv):
+        np.testing.assert_array_equal(g, e)
+
+
+def test_ragged_batch_vs_oracle():
+    """One launch, pairs of different lengths (ragged batch), chunked by a tiny budget."""
+    from oracle import oracle
+    from bialign_amd.batch import make_batch
+    from bialign_amd.engine import trace_codes_to_columns
+    shapes = [(40, 33), (5, 90), (90, 5), (64, 64), (1, 1), (17, 18), (100, 100), (2, 50)]
+    pairs = [synth.protein_pair(100 + t, n, m) for t, (n, m) in enumerate(shapes)]
+    params = dict(synth.PROTEIN_PARAMS)
+    for budget in (0, 12 << 20):
+        b = make_batch(pairs, params, hbm_budget_bytes=budget)
+        if budget:
+            assert b.info["nchunks"] > 1
+        b.run()
+        scores = b.scores()
+        traces, ok = b.traces()
+        for t, (sa, sb, ta, tb) in enumerate(pairs):
+            ref = oracle.solve(sa, sb, ta, tb, params)
+            assert int(scores[t]) == ref["score"]
+            assert trace_codes_to_columns(traces[t]) == oracle.trace_to_lists(ref["trace"])
+            assert bool(ok[t]) == ref["complete"]
+        b.close()
