@@ -1,0 +1,166 @@
+#!/usr/bin/env python3
+"""Headline benchmark: giga-DP-cells/s of the bi-alignment hot path on MI355X.
+
+One *step* = one pass of the hot path (affine DP fill + traceback, scores
+gathered) over one resident batch of synthetic pairs.  Workload at every N:
+BASELINE.json configs[1] per GPU -- 1024 synthetic protein pairs, len 512,
+BLOSUM62, affine gaps, max_shift=1 (rank r draws pairs seeded 1000 + r*1024 + p;
+weak scaling).  Pairs are independent, so ranks share nothing on the data path;
+the only collective is the final all_gather of int32 scores over RCCL.
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement").
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+
+
+def cpu_baseline(pairs, params, budget_s=18.0, max_pairs=8):
+    """The CPU oracle (oracle/bialign_oracle.c, a literal port of the reference
+    recurrence) timed on ONE host core on the first pairs of the same workload."""
+    from bialign_amd import synth
+    from oracle import oracle
+    n_done, cells, spent = 0, 0, 0.0
+    beta, gamma, delta, s = (params["gap_opening_cost"], params["gap_cost"], params["shift_cost"],
+                             params["max_shift"])
+    for sa, sb, ta, tb in pairs[:max_pairs]:
+        n, m = len(sa), len(sb)
+        mu1, mu2 = oracle.mu_tables(sa, sb, ta, tb, params)  # input preparation, not timed
+        t0 = time.perf_counter()
+        _, layers = oracle.affine_fill(n, m, s, beta, gamma, delta, mu1, mu2)
+        oracle.affine_traceback(n, m, s, beta, gamma, delta, mu1, mu2, layers)
+        spent += time.perf_counter() - t0
+        cells += synth.cells_per_pair(n, m, s)
+        n_done += 1
+        if spent > budget_s:
+            break
+    return {"value": cells / spent / 1e9, "unit": "Gcells/s", "cores": 1, "kind": "port",
+            "sample": f"first {n_done} pairs of the workload (fill+traceback, {cells} cells, "
+                      f"{spent:.1f} s on one host core)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--pairs", type=int, default=1024, help="pairs per GPU")
+    ap.add_argument("--len", type=int, default=512, dest="length")
+    ap.add_argument("--max_shift", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from bialign_amd import synth
+    from bialign_amd.batch import make_batch
+    from bialign_amd.engine import Engine
+
+    params = dict(synth.PROTEIN_PARAMS, max_shift=args.max_shift)
+    pairs = synth.protein_batch(args.pairs, args.length, seed0=1000 + rank * args.pairs)
+    engine = Engine(local_rank)
+    batch = make_batch(pairs, params, engine=engine)  # inputs now resident in HBM
+    info = batch.info
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    gathered = None
+
+    def step():
+        nonlocal gathered
+        batch.run()                      # fill + traceback, all chunks; returns when the device is done
+        scores = batch.scores()          # int32[pairs]
+        if world > 1:                    # the one collective: score gather over RCCL/xGMI
+            mine = torch.from_numpy(scores).cuda()
+            out = [torch.empty_like(mine) for _ in range(world)]
+            dist.all_gather(out, mine)
+            gathered = out
+        return scores
+
+    for _ in range(args.warmup):
+        step()
+    fill_ms = tb_ms = 0.0
+    launches = 0
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        t = batch.timing()               # HIP-event times on the engine's stream
+        fill_ms += t["fill_ms"]
+        tb_ms += t["traceback_ms"]
+        launches += t["fill_launches"]
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+        tot = torch.tensor([info["cells"], info["npairs"]], dtype=torch.int64, device="cuda")
+        dist.all_reduce(tot)
+        total_cells, total_pairs = int(tot[0].item()), int(tot[1].item())
+    else:
+        total_cells, total_pairs = info["cells"], info["npairs"]
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        fill_avg_ms = fill_ms / max(launches, 1)             # average fill-kernel launch
+        bytes_per_launch = info["layer_bytes"] / info["nchunks"]  # 36 B x cells of one launch
+        achieved = bytes_per_launch / (fill_avg_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(REPO, "profiles", "hbm_traffic.json")
+        if os.path.exists(tpath):
+            with open(tpath) as fh:
+                traffic = json.load(fh).get(f"protein_{args.pairs}x{args.length}_s{args.max_shift}")
+        line = {
+            "metric": "giga-DP-cells/sec", "value": total_cells * args.steps / elapsed / 1e9,
+            "unit": "Gcells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+            "pairs_per_s": total_pairs * args.steps / elapsed,
+            "config": {"workload": f"{args.pairs} synthetic protein pairs per GPU, len {args.length}, "
+                                   f"BLOSUM62, affine gaps (beta=-150, gamma=-50, Delta=-150, sw=800), "
+                                   f"max_shift={args.max_shift}; fill + traceback + score gather",
+                       "pairs_per_gpu": args.pairs, "len": args.length, "max_shift": args.max_shift,
+                       "cells_per_gpu": info["cells"], "chunks_per_step": info["nchunks"],
+                       "sharding": f"pairs sharded over {world} rank(s), no data-path collective"},
+            "kernel_ms": {"fill": fill_ms / args.steps, "traceback": tb_ms / args.steps},
+            "roofline": {"bound": "hbm", "kernel": "fill_affine_kernel", "achieved": achieved,
+                         "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+                         "traffic": traffic, "bytes_per_launch": bytes_per_launch,
+                         "avg_launch_ms": fill_avg_ms},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline(pairs, params)
+        elif not args.no_cpu_baseline:
+            line["cpu_baseline"] = None  # measured at N=1 only
+        print(json.dumps(line), flush=True)
+    batch.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
