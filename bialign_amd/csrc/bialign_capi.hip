@@ -126,7 +126,7 @@ namespace {
 
 size_t lds_need(int S, int NL, int k1, int k2, int n, int m) {
   const int W = 2 * S + 1, PADB = S + 1;
-  const size_t nv = (NL == 9 ? 20 : 4) * W;
+  const size_t nv = (NL == 9 ? 20 : 1) * W;
   const size_t npad = (n + 3) & ~3, mpad = (m + 2 * PADB + 3) & ~3;
   return (nv * NCOL + (size_t)k1 * k1 + (size_t)k2 * k2) * 4 + 2 * npad + 2 * mpad;
 }
@@ -158,6 +158,33 @@ int launch_traceback_affine(const bialign_batch* b, const DeviceBatch& v, int fi
   return BIALIGN_OK;
 }
 
+template <int S>
+int launch_fill_linear(const bialign_batch* b, const DeviceBatch& v, int first, int count) {
+  DeviceBatch w = v;
+  w.order = v.order + first;
+  auto kern = fill_linear_kernel<S>;
+  if (b->lds_bytes > 64 * 1024)
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_bytes));
+  hipLaunchKernelGGL(kern, dim3(count), dim3(64), b->lds_bytes, b->eng->stream, w);
+  HIP_TRY(hipGetLastError());
+  return BIALIGN_OK;
+}
+
+template <int S>
+int launch_traceback_linear(const bialign_batch* b, const DeviceBatch& v, int first, int count,
+                            bool do_trace) {
+  DeviceBatch w = v;
+  w.order = v.order + first;
+  const int blocks = (count + 63) / 64;
+  if (do_trace)
+    hipLaunchKernelGGL((traceback_linear_kernel<S, true>), dim3(blocks), dim3(64), 0, b->eng->stream, w, count);
+  else
+    hipLaunchKernelGGL((traceback_linear_kernel<S, false>), dim3(blocks), dim3(64), 0, b->eng->stream, w, count);
+  HIP_TRY(hipGetLastError());
+  return BIALIGN_OK;
+}
+
 int launch_fill(const bialign_batch* b, const DeviceBatch& v, int first, int count) {
   if (b->affine) {
     switch (b->S) {
@@ -165,6 +192,13 @@ int launch_fill(const bialign_batch* b, const DeviceBatch& v, int first, int cou
       case 1: return launch_fill_affine<1>(b, v, first, count);
       case 2: return launch_fill_affine<2>(b, v, first, count);
       case 3: return launch_fill_affine<3>(b, v, first, count);
+    }
+  } else {
+    switch (b->S) {
+      case 0: return launch_fill_linear<0>(b, v, first, count);
+      case 1: return launch_fill_linear<1>(b, v, first, count);
+      case 2: return launch_fill_linear<2>(b, v, first, count);
+      case 3: return launch_fill_linear<3>(b, v, first, count);
     }
   }
   return fail(BIALIGN_E_UNSUPPORTED, "no fill kernel for affine=%d max_shift=%d", b->affine, b->S);
@@ -177,6 +211,13 @@ int launch_traceback(const bialign_batch* b, const DeviceBatch& v, int first, in
       case 1: return launch_traceback_affine<1>(b, v, first, count, do_trace);
       case 2: return launch_traceback_affine<2>(b, v, first, count, do_trace);
       case 3: return launch_traceback_affine<3>(b, v, first, count, do_trace);
+    }
+  } else {
+    switch (b->S) {
+      case 0: return launch_traceback_linear<0>(b, v, first, count, do_trace);
+      case 1: return launch_traceback_linear<1>(b, v, first, count, do_trace);
+      case 2: return launch_traceback_linear<2>(b, v, first, count, do_trace);
+      case 3: return launch_traceback_linear<3>(b, v, first, count, do_trace);
     }
   }
   return fail(BIALIGN_E_UNSUPPORTED, "no traceback kernel for affine=%d max_shift=%d", b->affine, b->S);
@@ -196,6 +237,13 @@ int launch_dump_any(const bialign_batch* b, const DeviceBatch& v, int pid, int32
       case 1: return launch_dump<1, 9>(b, v, pid, d_out);
       case 2: return launch_dump<2, 9>(b, v, pid, d_out);
       case 3: return launch_dump<3, 9>(b, v, pid, d_out);
+    }
+  } else {
+    switch (b->S) {
+      case 0: return launch_dump<0, 1>(b, v, pid, d_out);
+      case 1: return launch_dump<1, 1>(b, v, pid, d_out);
+      case 2: return launch_dump<2, 1>(b, v, pid, d_out);
+      case 3: return launch_dump<3, 1>(b, v, pid, d_out);
     }
   }
   return fail(BIALIGN_E_UNSUPPORTED, "no dump kernel for affine=%d max_shift=%d", b->affine, b->S);

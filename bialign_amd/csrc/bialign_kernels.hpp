@@ -520,6 +520,238 @@ __global__ void __launch_bounds__(64) traceback_affine_kernel(const DeviceBatch 
 }
 
 // ---------------------------------------------------------------------------
+// Non-affine fill (pyx:443-471): one layer, thirteen cases (pyx:233-248).
+// Same lane mapping and skew as the affine sweep.  A lane publishes only its W
+// layer values per step; the three source lanes' values are read one step
+// later and kept in registers for the cases that need them 2 or 3 steps later
+// (age of offset o = o0 + o1 + o2).
+// ---------------------------------------------------------------------------
+template <int S>
+__global__ void __launch_bounds__(64) fill_linear_kernel(const DeviceBatch A) {
+  using G_ = Geo<S>;
+  using R_ = Rec<S, 1>;
+  constexpr int W = G_::W, R = G_::R, RR = G_::RR, PADB = G_::PADB;
+  constexpr int NV = W, ND = R_::ND, NCH4 = R_::NCH4, TAIL = R_::TAIL, RECDW = R_::RECDW;
+  extern __shared__ __align__(16) int32_t smem[];
+
+  const PairDesc pd = A.pairs[A.order[blockIdx.x]];
+  const int n = pd.n, m = pd.m, P = pd.P;
+  const int L = threadIdx.x;
+  const int il = L / W, aa = L - il * W;
+  const bool live = L < R * W;
+  const bool ghost = (il == 0);
+  const int gamma = A.gamma, delta = A.delta;
+  const int k1 = A.k1, k2 = A.k2;
+  const int gD = gamma + delta, gg = 2 * gamma;
+
+  int32_t* xch = smem;
+  int32_t* s1 = xch + NV * NCOL;
+  int32_t* s2 = s1 + k1 * k1;
+  const int npad = (n + 3) & ~3, mpad = (m + 2 * PADB + 3) & ~3;
+  uint8_t* sa = reinterpret_cast<uint8_t*>(s2 + k2 * k2);
+  uint8_t* ca = sa + npad;
+  uint8_t* sb = ca + npad;
+  uint8_t* cb = sb + mpad;
+
+  for (int t = L; t < NV * NCOL; t += 64) xch[t] = SENT;
+  for (int t = L; t < k1 * k1; t += 64) s1[t] = A.s1[t];
+  for (int t = L; t < k2 * k2; t += 64) s2[t] = A.s2[t];
+  for (int t = L; t < n; t += 64) {
+    sa[t] = A.seq_a[pd.seq_a + t];
+    ca[t] = A.cls_a[pd.seq_a + t];
+  }
+  for (int t = L; t < m + 2 * PADB; t += 64) {
+    const int src = t - PADB;
+    const bool ok = src >= 0 && src < m;
+    sb[t] = ok ? A.seq_b[pd.seq_b + src] : 0;
+    cb[t] = ok ? A.cls_b[pd.seq_b + src] : 0;
+  }
+  __syncthreads();
+
+  const int colLW = (live && il >= 1) ? L - W : 64;
+  const int colLW1 = (live && il >= 1 && aa < W - 1) ? L - W + 1 : 64;
+  const int colL1 = (live && il >= 1 && aa > 0) ? L - 1 : 64;
+  const int GOFF = P - 2 * (R - 1);
+  int32_t* const lay = A.layers + pd.layer_off;
+
+  int jj = -(2 * il + aa);
+  int strip = 0;
+  int i = 0, s1row = 0, s2row = 0;
+  bool act_row = false;
+  auto set_row = [&](int st) {
+    i = st * RR + il - 1;
+    const int k = i + aa - S;
+    act_row = live && i >= 0 && i <= n && k >= 0 && k <= n;
+    s1row = (i >= 1 && i <= n) ? sa[i - 1] * k1 : 0;
+    s2row = (k >= 1 && k <= n) ? ca[k - 1] * k2 : 0;
+  };
+  set_row(0);
+
+  int lw1[W], lw2[W];  // (i-1,a):   value seen 1 step ago (age 2), 2 steps ago (age 3)
+  int lwp1[W];         // (i-1,a+1): age 2
+  int l11[W];          // (i,a-1):   age 2
+  int selfM[W];        // own previous column
+  int ghostM[ND];
+#pragma unroll
+  for (int bb = 0; bb < W; ++bb) lw1[bb] = lw2[bb] = lwp1[bb] = l11[bb] = selfM[bb] = ghostM[bb] = SENT;
+
+  for (int g = 0; g < pd.G; ++g) {
+    int inLW[W], inLW1[W], inL1[W];
+#pragma unroll
+    for (int bb = 0; bb < W; ++bb) {
+      inLW[bb] = xch[bb * NCOL + colLW];
+      inLW1[bb] = xch[bb * NCOL + colLW1];
+      inL1[bb] = xch[bb * NCOL + colL1];
+    }
+    const int jc = min(max(jj, 0), m + 1);
+    const int mu1 = s1[s1row + sb[jc - 1 + PADB]];
+    int mu2[W];
+#pragma unroll
+    for (int bb = 0; bb < W; ++bb) mu2[bb] = s2[s2row + cb[jc + bb]];
+
+    const bool tile_act = act_row && jj >= 0 && jj <= m;
+    const bool is_origin = tile_act && i == 0 && jj == 0 && aa == S;
+    const int c4 = mu1 + delta, c12 = mu1 + gD;
+
+    int outv[ND];
+    int prev = SENT;  // value of point bb-1 of this step (case (0,0,0,1))
+#pragma unroll
+    for (int bb = 0; bb < W; ++bb) {
+      const int l = jj + bb - S;
+      const bool act = tile_act && l >= 0 && l <= m;
+      const int mu2v = mu2[bb];
+      const int c5 = mu2v + delta, c10 = mu2v + gD;
+      // the thirteen cases in generator order (pyx:233-248); b-band violations are static
+      int t = (mu1 + mu2v) + lw2[bb];                    // (1,1,1,1)
+      t = imax(t, gg + lw1[bb]);                         // (1,0,1,0)
+      t = imax(t, gg + selfM[bb]);                       // (0,1,0,1)
+      if (bb + 1 < W) t = imax(t, c4 + lwp1[bb + 1 < W ? bb + 1 : 0]);   // (1,1,0,0)
+      if (bb >= 1) t = imax(t, c5 + inL1[bb >= 1 ? bb - 1 : 0]);         // (0,0,1,1)
+      t = imax(t, gD + inLW1[bb]);                       // (1,0,0,0)
+      if (bb + 1 < W) t = imax(t, gD + selfM[bb + 1 < W ? bb + 1 : 0]);  // (0,1,0,0)
+      t = imax(t, gD + inL1[bb]);                        // (0,0,1,0)
+      if (bb >= 1) t = imax(t, gD + prev);               // (0,0,0,1)
+      if (bb >= 1) t = imax(t, c10 + lw1[bb >= 1 ? bb - 1 : 0]);         // (1,0,1,1)
+      t = imax(t, c10 + l11[bb]);                        // (0,1,1,1)
+      if (bb + 1 < W) t = imax(t, c12 + lw2[bb + 1 < W ? bb + 1 : 0]);   // (1,1,1,0)
+      t = imax(t, c12 + lwp1[bb]);                       // (1,1,0,1)
+
+      const int tv = ghost ? ghostM[bb] : t;
+      const bool bad = (tv < THRESH) | !act;
+      int M = bad ? (act ? NEG : SENT) : tv;             // pyx:299-303
+      if (bb == S) M = is_origin ? 0 : M;                // np.zeros origin (pyx:27, 464-465)
+      outv[bb] = M;
+      prev = M;
+    }
+#pragma unroll
+    for (int bb = 0; bb < W; ++bb) {
+      xch[bb * NCOL + L] = outv[bb];
+      selfM[bb] = outv[bb];
+      lw2[bb] = lw1[bb];
+      lw1[bb] = inLW[bb];
+      lwp1[bb] = inLW1[bb];
+      l11[bb] = inL1[bb];
+    }
+
+    if (ghost && live) {
+      int nj = jj + 1, nstrip = strip;
+      if (nj == P) { nj = 0; ++nstrip; }
+      if (nstrip >= 1 && nj >= 0 && nj <= m) {
+        const int32_t* src = lay + (int64_t)(g + 1 - GOFF) * RECDW;
+        const int sl = L + (R - 1) * W;
+#pragma unroll
+        for (int c = 0; c < NCH4; ++c) {
+          const v4i v = __builtin_nontemporal_load(reinterpret_cast<const v4i*>(src + c * 256 + sl * 4));
+          ghostM[4 * c] = v.x; ghostM[4 * c + 1] = v.y; ghostM[4 * c + 2] = v.z; ghostM[4 * c + 3] = v.w;
+        }
+#pragma unroll
+        for (int t = 0; t < TAIL; ++t)
+          ghostM[4 * NCH4 + t] = __builtin_nontemporal_load(src + NCH4 * 256 + sl * TAIL + t);
+      }
+    }
+    if (tile_act && !ghost) {
+      int32_t* dst = lay + (int64_t)g * RECDW;
+#pragma unroll
+      for (int c = 0; c < NCH4; ++c) {
+        v4i v;
+        v.x = outv[4 * c]; v.y = outv[4 * c + 1]; v.z = outv[4 * c + 2]; v.w = outv[4 * c + 3];
+        *reinterpret_cast<v4i*>(dst + c * 256 + L * 4) = v;
+      }
+#pragma unroll
+      for (int t = 0; t < TAIL; ++t) dst[NCH4 * 256 + L * TAIL + t] = outv[4 * NCH4 + t];
+    }
+    ++jj;
+    if (jj == P) {
+      jj = 0;
+      ++strip;
+      set_row(strip);
+    }
+  }
+}
+
+// Non-affine traceback (pyx:513-531): first case, in generator order, that is
+// guard-valid and reproduces the cell; stops when none does (the origin).
+template <int S, bool DO_TRACE>
+__global__ void __launch_bounds__(64) traceback_linear_kernel(const DeviceBatch A, int npairs) {
+  const int slot = blockIdx.x * 64 + threadIdx.x;
+  if (slot >= npairs) return;
+  const int pid = A.order[slot];
+  const PairDesc pd = A.pairs[pid];
+  const int n = pd.n, m = pd.m;
+  const int gamma = A.gamma, delta = A.delta;
+  const int32_t* lay = A.layers;
+  const uint8_t* sa = A.seq_a + pd.seq_a;
+  const uint8_t* ca = A.cls_a + pd.seq_a;
+  const uint8_t* sb = A.seq_b + pd.seq_b;
+  const uint8_t* cb = A.cls_b + pd.seq_b;
+  int cur = lay[cell_dword<S, 1>(pd, n, m, S, S, 0)];
+  A.scores[pid] = cur;  // pyx:471
+  if (!DO_TRACE) return;
+
+  // offsets of the thirteen cases as bit masks o0*8+o1*4+o2*2+o3 (pyx:233-248)
+  constexpr int OFF[13] = {15, 10, 5, 12, 3, 8, 4, 2, 1, 11, 7, 14, 13};
+  uint8_t* out = A.trace + pd.trace_off;
+  int i = n, j = m, k = n, l = m, len = 0;
+  while (true) {
+    const int mu1 = (i >= 1 && j >= 1) ? A.s1[sa[i - 1] * A.k1 + sb[j - 1]] : 0;
+    const int mu2 = (k >= 1 && l >= 1) ? A.s2[ca[k - 1] * A.k2 + cb[l - 1]] : 0;
+    const int gD = gamma + delta;
+    const int sc[13] = {mu1 + mu2, 2 * gamma, 2 * gamma, mu1 + delta, mu2 + delta, gD, gD, gD, gD,
+                        gD + mu2, gD + mu2, gD + mu1, gD + mu1};
+    int ld[13];
+    bool ok[13];
+#pragma unroll
+    for (int c = 0; c < 13; ++c) {
+      const int o0 = (OFF[c] >> 3) & 1, o1 = (OFF[c] >> 2) & 1, o2 = (OFF[c] >> 1) & 1, o3 = OFF[c] & 1;
+      const int pi = i - o0, pj = j - o1, pk = k - o2, pl = l - o3;
+      ok[c] = pi >= 0 && pj >= 0 && pk >= 0 && pl >= 0 && abs(pk - pi) <= S && abs(pl - pj) <= S;
+      ld[c] = ok[c] ? lay[cell_dword<S, 1>(pd, pi, pj, pk - pi + S, pl - pj + S, 0)] : 0;
+    }
+    int pick = -1, nxt = 0;
+#pragma unroll
+    for (int c = 12; c >= 0; --c)
+      if (ok[c] && ld[c] + sc[c] == cur) { pick = c; nxt = ld[c]; }
+    if (pick < 0) break;
+    int code = 0;
+#pragma unroll
+    for (int c = 0; c < 13; ++c)
+      if (c == pick) code = OFF[c];
+    if (len < pd.trace_cap) out[len] = (uint8_t)code;
+    ++len;
+    i -= (code >> 3) & 1; j -= (code >> 2) & 1; k -= (code >> 1) & 1; l -= code & 1;
+    cur = nxt;
+  }
+  if (len > pd.trace_cap) len = pd.trace_cap;
+  for (int x = 0, y = len - 1; x < y; ++x, --y) {
+    const uint8_t t = out[x];
+    out[x] = out[y];
+    out[y] = t;
+  }
+  A.trace_len[pid] = len;
+  A.complete[pid] = 1;
+}
+
+// ---------------------------------------------------------------------------
 // Layer dump in the reference layout (tests only).
 // ---------------------------------------------------------------------------
 template <int S, int NL>

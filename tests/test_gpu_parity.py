@@ -90,7 +90,7 @@ def test_ragged_batch_vs_oracle():
     shapes = [(40, 33), (5, 90), (90, 5), (64, 64), (1, 1), (17, 18), (100, 100), (2, 50)]
     pairs = [synth.protein_pair(100 + t, n, m) for t, (n, m) in enumerate(shapes)]
     params = dict(synth.PROTEIN_PARAMS)
-    for budget in (0, 12 << 20):
+    for budget in (0, 5 << 20):
         b = make_batch(pairs, params, hbm_budget_bytes=budget)
         if budget:
             assert b.info["nchunks"] > 1
