@@ -10,8 +10,9 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libbialign_hip.so")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 RUN_FILL_ONLY = 1
+REC_AUTO, REC_AFFINE, REC_LINEAR = 0, 1, 2
 MAX_SHIFT = 3
 
 E_INVALID, E_UNSUPPORTED, E_DEVICE, E_NOMEM, E_RANGE = -1, -2, -3, -4, -5
@@ -23,7 +24,8 @@ c_u8p = ctypes.POINTER(ctypes.c_uint8)
 
 class Params(ctypes.Structure):
     _fields_ = [("gap_opening_cost", ctypes.c_int32), ("gap_cost", ctypes.c_int32),
-                ("shift_cost", ctypes.c_int32), ("max_shift", ctypes.c_int32)]
+                ("shift_cost", ctypes.c_int32), ("max_shift", ctypes.c_int32),
+                ("recurrence", ctypes.c_int32)]
 
 
 class Scoring(ctypes.Structure):

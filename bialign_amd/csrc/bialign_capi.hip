@@ -313,7 +313,10 @@ int bialign_batch_create(bialign_engine* eng, const bialign_params* prm, const b
   std::unique_ptr<bialign_batch> b(new bialign_batch());
   b->eng = eng;
   b->prm = *prm;
-  b->affine = prm->gap_opening_cost != 0;  // pyx:204-205
+  if (prm->recurrence < BIALIGN_REC_AUTO || prm->recurrence > BIALIGN_REC_LINEAR)
+    return fail(BIALIGN_E_INVALID, "recurrence must be 0 (auto), 1 (affine) or 2 (non-affine)");
+  b->affine = prm->recurrence == BIALIGN_REC_AUTO ? prm->gap_opening_cost != 0  // pyx:204-205, 444
+                                                  : prm->recurrence == BIALIGN_REC_AFFINE;
   b->NL = b->affine ? 9 : 1;
   b->S = prm->max_shift;
   b->npairs = pr->npairs;

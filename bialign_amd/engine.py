@@ -59,7 +59,7 @@ class Batch:
     """
 
     def __init__(self, engine, mols_a, mols_b, s1, s2, gap_opening_cost, gap_cost, shift_cost,
-                 max_shift, hbm_budget_bytes=0):
+                 max_shift, hbm_budget_bytes=0, recurrence=0):
         if len(mols_a) != len(mols_b) or not mols_a:
             raise ValueError("need the same, non-zero number of A and B molecules")
         self.engine = engine
@@ -83,7 +83,8 @@ class Batch:
             raise ValueError("sequence code outside the S1 table")
         if cls_a.size and (cls_a.max() >= s2.shape[0] or cls_b.max() >= s2.shape[0]):
             raise ValueError("structure class outside the S2 table")
-        prm = _lib.Params(int(gap_opening_cost), int(gap_cost), int(shift_cost), int(max_shift))
+        prm = _lib.Params(int(gap_opening_cost), int(gap_cost), int(shift_cost), int(max_shift),
+                          int(recurrence))
         sc = _lib.Scoring(s1.shape[0], _ptr(s1, ctypes.c_int32), s2.shape[0], _ptr(s2, ctypes.c_int32))
         pr = _lib.Pairs(self.npairs, _ptr(self.len_a, ctypes.c_int32), _ptr(self.len_b, ctypes.c_int32),
                         _ptr(off_a, ctypes.c_int64), _ptr(off_b, ctypes.c_int64),

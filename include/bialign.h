@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define BIALIGN_ABI_VERSION 1
+#define BIALIGN_ABI_VERSION 2
 
 #define BIALIGN_OK 0
 #define BIALIGN_E_INVALID (-1)     /* bad argument (message says which) */
@@ -40,6 +40,11 @@ extern "C" {
 
 #define BIALIGN_MAX_SHIFT 3 /* kernels are instantiated for max_shift 0..3 */
 #define BIALIGN_NEG_INF (-(1 << 30)) /* the reference's -infinity, pyx:303,484 */
+
+/* bialign_params.recurrence */
+#define BIALIGN_REC_AUTO 0
+#define BIALIGN_REC_AFFINE 1
+#define BIALIGN_REC_LINEAR 2
 
 /* run flags */
 #define BIALIGN_RUN_FILL_ONLY 1u /* optimize() without traceback() */
@@ -53,6 +58,9 @@ typedef struct bialign_params {
   int32_t gap_cost;         /* gamma */
   int32_t shift_cost;       /* Delta */
   int32_t max_shift;        /* s, 0..BIALIGN_MAX_SHIFT */
+  int32_t recurrence;       /* BIALIGN_REC_AUTO: affine iff gap_opening_cost != 0, as optimize()
+                               dispatches (pyx:444); BIALIGN_REC_AFFINE = affine_optimize() called
+                               directly (pyx:474); BIALIGN_REC_LINEAR = the 13-case recurrence */
 } bialign_params;
 
 /* Score tables, row-major, values already scaled (nonpyx:33: x100). */

@@ -1,0 +1,130 @@
+"""GPU: the drop-in API (BiAligner, CLI) end to end against the compiled
+reference's outputs, plus size-independent properties at BASELINE sizes."""
+import contextlib
+import io
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, load_golden
+from bialign_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+KNOWN = load_golden("known_answers.json")
+SMALL = load_golden("small_layers.json")
+CLI = load_golden("cli_outputs.json")
+
+
+def supported(rec):
+    return rec["params"]["max_shift"] <= 3
+
+
+@pytest.mark.parametrize("rec", [r for r in KNOWN + SMALL if supported(r)], ids=lambda r: r["name"])
+def test_bialigner_end_to_end(rec):
+    from bialign_amd import bialignment as ba
+    b = ba.BiAligner(rec["seqA"], rec["seqB"], rec["strA"], rec["strB"], **rec["params"])
+    score = b.optimize()
+    assert isinstance(score, np.int64) and int(score) == rec["score"]
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        trace = b.traceback()
+    affine = rec["params"]["gap_opening_cost"] != 0
+    assert trace == [list(c) if affine else tuple(c) for c in rec["trace"]]
+    assert ("WARNING: incomplete traceback" in buf.getvalue()) == (not rec["complete"])
+    assert [[n, s] for n, s in b.decode_trace_full()] == rec["decode_full"]
+    assert b.decode_trace() == rec["decode"]["default"]["lines"]
+    assert list(b.eval_trace()) == rec["eval_trace"]   # non-affine: reads layers back through eval_case
+
+
+def test_layer_containers_match_reference_types():
+    from bialign_amd import bialignment as ba
+    rec = next(r for r in KNOWN if r["name"] == "protein_2mer")
+    b = ba.BiAligner(rec["seqA"], rec["seqB"], rec["strA"], rec["strB"], **rec["params"])
+    b.optimize()
+    # SURVEY.md appendix A worked example: target (1,0,1,1) at (1,1,1,2)
+    cases = list(b.affine_recursion_cases((1, 0, 1, 1), (1, 1, 1, 2)))
+    assert len(cases) == 15
+    assert [c[2] for c in cases[9:12]] == [500, 500, 500]
+    assert [c[2] for c in cases[12:]] == [-350, -200, -350]
+    layer = b._layers()[(1, 1, 1, 1)]
+    assert layer[0, 0, 0, 0] == 0 and b._layers()[(1, 0, 1, 0)][0, 0, 0, 0] == -(1 << 30)
+
+
+@pytest.mark.parametrize("name", list(CLI))
+def test_cli_stdout(name, capsys):
+    from bialign_amd import cli
+    rec = CLI[name]
+    if any(a == "--max_shift" for a in rec["args"]) is False and "--outmode" in rec["args"] and "help" in rec["args"]:
+        pass
+    try:
+        cli.main(rec["args"])
+    except SystemExit:
+        pass
+    assert capsys.readouterr().out == rec["stdout"]
+
+
+def test_cli_dnapol_config3(capsys):
+    """BASELINE config 3: DNA-Pol-I E. coli (928 aa) vs Xanthomonas (933 aa); the
+    fixture is the reference CLI's stdout (score 761500, 1022 columns)."""
+    from bialign_amd import cli
+    with open(os.path.join(GOLDEN, "dnapol_cli_stdout.txt")) as fh:
+        want = fh.read()
+    lines = want.split("\n")
+    seq_a, seq_b, str_a, str_b = (lines[t].split("\t ")[1] for t in (1, 2, 3, 4))
+    assert (len(seq_a), len(seq_b)) == (928, 933) and "SCORE: 761500" in want
+    cli.main([seq_a, seq_b, "--strA", str_a, "--strB", str_b, "--type", "Protein", "--shift_cost", "-150",
+              "--structure_weight", "800", "--simmatrix", "BLOSUM62", "--gap_opening_cost", "-150",
+              "--gap_cost", "-50", "--max_shift", "1"])
+    assert capsys.readouterr().out == want
+
+
+def _property_check(pairs, params):
+    from bialign_amd.batch import encode_pairs
+    from bialign_amd.engine import Batch, default_engine
+    from bialign_amd.verify import rescore_trace
+    model, mols_a, mols_b = encode_pairs(pairs, params)
+    b = Batch(default_engine(), mols_a, mols_b, model.s1, model.s2, params["gap_opening_cost"],
+              params["gap_cost"], params["shift_cost"], params["max_shift"])
+    b.run()
+    scores = b.scores()
+    traces, ok = b.traces()
+    affine = params["gap_opening_cost"] != 0
+    for p, (sa, sb, _, _) in enumerate(pairs):
+        total, consumed, drift = rescore_trace(traces[p], mols_a[p][0], mols_a[p][1], mols_b[p][0], mols_b[p][1],
+                                               model.s1, model.s2, params["gap_opening_cost"],
+                                               params["gap_cost"], params["shift_cost"], affine)
+        assert ok[p]
+        assert total == int(scores[p])                       # trace re-scores to the optimum
+        assert consumed == (len(sa), len(sb), len(sa), len(sb))  # consumes exactly (n,m,n,m)
+        assert drift <= params["max_shift"]                   # never leaves the band
+    info = b.info
+    b.close()
+    return info
+
+
+def test_properties_config2_shape():
+    """BASELINE config 2 shape (len 512, s=1), 96 of the 1024 seeded pairs."""
+    pairs = synth.protein_batch(96, 512)
+    info = _property_check(pairs, dict(synth.PROTEIN_PARAMS))
+    assert info["cells"] == 96 * 1537 * 1537
+
+
+def test_properties_config5_shape():
+    """BASELINE config 5 shape (len 1024, s=1), 24 pairs."""
+    _property_check(synth.protein_batch(24, 1024), dict(synth.PROTEIN_PARAMS))
+
+
+def test_properties_config4_shape():
+    """BASELINE config 4 shape: RNA, len 2000, dot-bracket structures, s=2 (3.6 GB of layers per pair)."""
+    params = dict(synth.RNA_PARAMS, max_shift=2)
+    info = _property_check(synth.rna_batch(6, 2000), params)
+    assert info["cells"] == 6 * 9999 * 9999
+
+
+def test_properties_linear_and_wide_band():
+    _property_check(synth.protein_batch(16, 300, 257),
+                    dict(synth.PROTEIN_PARAMS, gap_opening_cost=0, gap_cost=-200, shift_cost=-250, max_shift=2))
+    _property_check(synth.protein_batch(8, 200, 333), dict(synth.PROTEIN_PARAMS, max_shift=3))
+    _property_check(synth.rna_batch(8, 400), dict(synth.RNA_PARAMS, max_shift=0))

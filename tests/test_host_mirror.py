@@ -1,0 +1,140 @@
+"""Host-side mirror of the reference API (no GPU needed): score inputs, trace
+decoding in every output mode, trace evaluation -- against the golden vectors
+of the compiled reference."""
+import contextlib
+import io
+
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from bialign_amd import bialignment as ba
+from bialign_amd import scoring, synth
+from bialign_amd.batch import encode_pairs, shard
+from oracle import oracle
+
+KNOWN = load_golden("known_answers.json")
+SMALL = load_golden("small_layers.json")
+MEDIUM = load_golden("medium_traces.json")
+DECODED = [r for r in KNOWN + SMALL + MEDIUM if "decode_full" in r]
+
+
+def aligner(rec, **extra):
+    return ba.BiAligner(rec["seqA"], rec["seqB"], rec["strA"], rec["strB"], **dict(rec["params"], **extra))
+
+
+def as_trace(rec):
+    affine = rec["params"]["gap_opening_cost"] != 0
+    return [list(c) if affine else tuple(c) for c in rec["trace"]]
+
+
+@pytest.mark.parametrize("rec", DECODED, ids=[r["name"] for r in DECODED])
+def test_decode_trace_full(rec):
+    got = aligner(rec).decode_trace_full(as_trace(rec))
+    assert [[n, s] for n, s in got] == rec["decode_full"]
+
+
+@pytest.mark.parametrize("rec", DECODED, ids=[r["name"] for r in DECODED])
+def test_decode_trace_modes(rec):
+    for mode, want in rec["decode"].items():
+        b = aligner(rec, outmode=mode)
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            lines = b.decode_trace(as_trace(rec))
+        assert lines == want["lines"], mode
+        assert buf.getvalue() == want["stdout"], mode
+    assert aligner(rec, nodescription=True).decode_trace(as_trace(rec)) == rec["decode_nodescription"]
+
+
+@pytest.mark.parametrize("rec", [r for r in DECODED if r["params"]["gap_opening_cost"] != 0],
+                         ids=lambda r: r["name"])
+def test_eval_affine_trace(rec):
+    assert list(aligner(rec).eval_trace(as_trace(rec))) == rec["eval_trace"]
+    # free self-check of any trace: the column scores add up to the optimum
+    last = rec["eval_trace"][-1].split()[-1]
+    assert int(last) == rec["score"]
+
+
+@pytest.mark.parametrize("rec", KNOWN + SMALL[:8] + SMALL[-4:], ids=lambda r: r["name"])
+def test_lookup_tables_match_reference_mu(rec):
+    """codes + tables reproduce mu1/mu2 of the plain restatement for every (i,j)."""
+    p = rec["params"]
+    model, mols_a, mols_b = encode_pairs([(rec["seqA"], rec["seqB"], rec["strA"], rec["strB"])], p)
+    mu1, mu2 = oracle.mu_tables(rec["seqA"], rec["seqB"], rec["strA"], rec["strB"], p)
+    (ca, ka), (cb, kb) = mols_a[0], mols_b[0]
+    np.testing.assert_array_equal(model.s1[ca][:, cb], mu1[1:, 1:])
+    np.testing.assert_array_equal(model.s2[ka][:, kb], mu2[1:, 1:])
+    b = aligner(rec)
+    n, m = len(rec["seqA"]), len(rec["seqB"])
+    for i, j in [(1, 1), (n, m), (1, m), (n, 1), ((n + 1) // 2, (m + 1) // 2)]:
+        assert b.mu1(i, j) == mu1[i, j]
+        assert b.mu2(i, j) == mu2[i, j]
+
+
+def test_rna_classes_edge_cases():
+    # "()" : the closing bracket's partner is i-1, which range(1, i-1) skips (pyx:367-369)
+    assert list(scoring.rna_classes("()")) == [scoring.RNA_DOWN, scoring.RNA_UNP]
+    assert list(scoring.rna_classes("(.)")) == [scoring.RNA_DOWN, scoring.RNA_UNP, scoring.RNA_UP]
+    assert list(scoring.rna_classes("x[.")) == [scoring.RNA_UNP] * 3
+    with pytest.raises(IndexError):
+        scoring.rna_classes("())")
+
+
+def test_simmatrix_and_unknown_residue():
+    sim = ba.read_simmatrix("BLOSUM62")
+    assert sim["W"]["W"] == 1100 and sim["A"]["R"] == -100 and sim["*"]["*"] == 100
+    assert ba.blosum62.splitlines()[0].split() == ["-"] + list("ARNDCQEGHILKMFPSTWYVBZX*")
+    model = scoring.ScoreModel(dict(synth.PROTEIN_PARAMS))
+    with pytest.raises(KeyError):
+        model.encode_sequence("AJA")  # J is not a BLOSUM62 key (reference: KeyError in mu1)
+
+
+def test_simmatrix_user_file(tmp_path):
+    f = tmp_path / "m.txt"
+    f.write_text("-  A  C\nA  2 -1\nC -1  3\n")
+    assert ba.read_simmatrix(str(f)) == {"A": {"A": 200, "C": -100}, "C": {"A": -100, "C": 300}}
+
+
+def test_constructor_errors(capsys):
+    with pytest.raises(SystemExit):
+        ba.BiAligner("ACGU", "ACG", "....", "..", **synth.RNA_PARAMS)
+    assert "ERROR: Provided structure and sequence must have the same length." in capsys.readouterr().out
+    with pytest.raises(SystemExit):
+        ba.BiAligner("ACD", "ACD", None, None, **synth.PROTEIN_PARAMS)
+    assert "ERROR: Structures have to be provided when aligning proteins" in capsys.readouterr().out
+
+
+def test_module_surface():
+    for name in ("SparseMatrix4D", "AffineDPMatrices", "guard_case", "argmin", "BiAligner", "mea",
+                 "consensus_sequence", "consensus_sbpp", "parse_dotbracket", "highlight_sequence_identity",
+                 "highlight_structure_identity", "highlight_structure_similarity", "blosum62",
+                 "read_simmatrix", "read_molecule", "read_molecule_from_file", "breaklines", "runs",
+                 "fourway_from_full", "plot_alignment", "helix_yadd_a", "helix_yadd_b", "__version__"):
+        assert hasattr(ba, name), name
+    assert ba.BiAligner.nl == 14 and list(ba.BiAligner.outmodes) == [
+        "default", "sorted", "sorted_sym", "sorted_terse", "raw", "raw_struct", "full"]
+    assert ba.guard_case((1, 1, 1, 1), (1, 1, 1, 1), 0) and not ba.guard_case((1, 0, 0, 0), (1, 1, 2, 1), 1)
+    assert ba.argmin([[2, 1], [1, 5], [1, 5]]) == 1
+    m = ba.AffineDPMatrices(2, 3, 1)
+    assert len(m.states) == 9 and m.states[0] == (0, 1, 0, 1) and m.states[-1] == (1, 1, 1, 1)
+    m[(1, 0, 1, 1)][1, 2, 2, 3] = 7
+    assert m[(1, 0, 1, 1)][1, 2, 2, 3] == 7
+
+
+def test_read_molecule():
+    text = "Query 1 MVQ 3\nStruc 1 HHC 3\n\nQuery 4 IP 5\nStruc 4 EE 5\nTotal Residues: H: 2\n"
+    assert ba.read_molecule(text, "Protein") == ["MVQIP", "HHCEE"]
+    with pytest.raises(IOError):
+        ba.read_molecule(text, "RNA")
+    with pytest.raises(IOError):
+        ba.read_molecule("Query 1 MV 2\nStruc 1 H 1\n", "Protein")
+    assert list(ba.runs("HHHCC-")) == [("H", 0, 3), ("C", 3, 5), ("-", 5, 6)]
+    assert ba.breaklines([("a", "abcdef"), ("b", "ABCDEF")], 4) == [
+        [("a", "abcd"), ("b", "ABCD")], [("a", "ef"), ("b", "EF")]]
+
+
+def test_shard_partition():
+    for n, w in [(8192, 8), (10, 4), (3, 8)]:
+        got = [list(shard(n, r, w)) for r in range(w)]
+        assert sum(got, []) == list(range(n))
+        assert max(map(len, got)) - min(map(len, got)) <= 1
