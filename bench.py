@@ -87,18 +87,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    gathered = None
+    from bialign_amd.distributed import gather_scores
 
     def step():
-        nonlocal gathered
         batch.run()                      # fill + traceback, all chunks; returns when the device is done
-        scores = batch.scores()          # int32[pairs]
-        if world > 1:                    # the one collective: score gather over RCCL/xGMI
-            mine = torch.from_numpy(scores).cuda()
-            out = [torch.empty_like(mine) for _ in range(world)]
-            dist.all_gather(out, mine)
-            gathered = out
-        return scores
+        scores = batch.scores()          # int32[pairs] of this rank
+        # the one collective: all_gather of the scores over RCCL/xGMI (no-op at N=1)
+        return gather_scores(scores, args.pairs * world)
 
     for _ in range(args.warmup):
         step()

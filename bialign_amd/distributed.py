@@ -1,0 +1,77 @@
+"""One-process-per-GPU sharding of a batch.
+
+Pairs are independent (the reference builds one BiAligner per pair,
+bialign.py:11), so ranks own contiguous blocks of pairs and never exchange DP
+data.  The single collective is the final gather of int32 scores (4 B/pair):
+``torch.distributed`` all_gather -- RCCL over xGMI with the "nccl" backend on
+the GPUs, gloo on CPU for the tests.
+"""
+import numpy as np
+
+from .batch import shard
+
+
+def init_from_env(backend=None):
+    """Initialise torch.distributed from RANK/WORLD_SIZE/MASTER_* (torchrun)."""
+    import os
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        kwargs = {}
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            kwargs["device_id"] = torch.device("cuda", local_rank)
+        dist.init_process_group(backend, **kwargs)
+    return rank, local_rank, world
+
+
+def gather_scores(local_scores, npairs_total):
+    """All ranks -> the full int32 score vector in global pair order.
+
+    ``local_scores`` are this rank's scores for ``shard(npairs_total, rank, world)``.
+    """
+    import torch
+    import torch.distributed as dist
+    local = np.ascontiguousarray(local_scores, dtype=np.int32)
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        assert len(local) == npairs_total
+        return local.copy()
+    world, rank = dist.get_world_size(), dist.get_rank()
+    assert len(local) == len(shard(npairs_total, rank, world))
+    width = -(-npairs_total // world)  # shards differ by at most one pair: pad to the widest
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+    mine = torch.zeros(width, dtype=torch.int32, device=dev)
+    mine[:len(local)] = torch.from_numpy(local).to(dev)
+    parts = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(parts, mine)
+    out = np.empty(npairs_total, dtype=np.int32)
+    for r, part in enumerate(parts):
+        blk = shard(npairs_total, r, world)
+        out[blk.start:blk.stop] = part[:len(blk)].cpu().numpy()
+    return out
+
+
+def align_sharded(pairs, params, device=None, hbm_budget_bytes=0):
+    """Align this rank's shard of ``pairs`` on its GPU; every rank returns the
+    scores of ALL pairs (gathered) and the traces of its own shard."""
+    import torch.distributed as dist
+    from .batch import make_batch
+    from .engine import Engine
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    mine = shard(len(pairs), rank, world)
+    if device is None:
+        import torch
+        device = torch.cuda.current_device()
+    batch = make_batch([pairs[p] for p in mine], params, engine=Engine(device),
+                       hbm_budget_bytes=hbm_budget_bytes)
+    batch.run()
+    traces, complete = batch.traces()
+    scores = gather_scores(batch.scores(), len(pairs))
+    batch.close()
+    return scores, {p: (traces[t], bool(complete[t])) for t, p in enumerate(mine)}
