@@ -66,8 +66,10 @@ struct DevBuf {
 // Sweep geometry of one pair (mirrors the kernel's Geo<S>): strips, period, steps.
 void sweep_geometry(int n, int m, int S, int* NS, int* P, int* G) {
   const int W = 2 * S + 1, R = 64 / W, RR = R - 1;
+  const int min_goff = 2 * (S <= 1 ? 16 : (S == 2 ? 8 : 4)) + 8;  // GhostFeed<S,.>::MIN_GOFF
   *NS = (n + 1 + RR - 1) / RR;
-  *P = std::max(m + 2, 2 * (R - 1) + 8);
+  // one idle column between strips (P >= m+2) and ghost records old enough to prefetch
+  *P = std::max(m + 2, 2 * (R - 1) + min_goff);
   *G = (*NS - 1) * *P + m + 2 * (R - 1) + (W - 1) + 1;
 }
 
@@ -128,7 +130,9 @@ size_t lds_need(int S, int NL, int k1, int k2, int n, int m) {
   const int W = 2 * S + 1, PADB = S + 1;
   const size_t nv = (NL == 9 ? 20 : 1) * W;
   const size_t npad = (n + 3) & ~3, mpad = (m + 2 * PADB + 3) & ~3;
-  return (nv * NCOL + (size_t)k1 * k1 + (size_t)k2 * k2) * 4 + 2 * npad + 2 * mpad;
+  const int nd = NL * W, np = nd / 4 + (nd % 4 ? 1 : 0), blk = S <= 1 ? 16 : (S == 2 ? 8 : 4);
+  const size_t ring_dw = 2 * (((size_t)blk * W * np + 63) / 64 * 64) * 4;  // GhostFeed<S,NL>::RING_DW
+  return (ring_dw + nv * NCOL + (size_t)k1 * k1 + (size_t)k2 * k2) * 4 + 2 * npad + 2 * mpad;
 }
 
 template <int S>
@@ -398,7 +402,7 @@ int bialign_batch_create(bialign_engine* eng, const bialign_params* prm, const b
   HIP_TRY(b->d_cls_a.upload(pr->cls_a, tot_a, st));
   HIP_TRY(b->d_seq_b.upload(pr->seq_b, tot_b, st));
   HIP_TRY(b->d_cls_b.upload(pr->cls_b, tot_b, st));
-  HIP_TRY(b->d_layers.alloc(b->max_chunk_dwords));
+  HIP_TRY(b->d_layers.alloc(b->max_chunk_dwords + 16));  // slack: ghost tail pieces are read 16 B wide
   HIP_TRY(b->d_scores.alloc(pr->npairs));
   HIP_TRY(b->d_tlen.alloc(pr->npairs));
   HIP_TRY(b->d_complete.alloc(pr->npairs));

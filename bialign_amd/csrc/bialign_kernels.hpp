@@ -100,6 +100,72 @@ __host__ __device__ inline int64_t cell_dword(const PairDesc& pd, int i, int j, 
   return pd.layer_off + Rec<S, NL>::dword(g, il * W + aa, bb * NL + st);
 }
 
+
+// ---------------------------------------------------------------------------
+// Ghost-row feed.  The first lane row of a strip replays the last row of the
+// previous strip, whose layers already sit in HBM (they are output anyway), so
+// strips exchange nothing but what the sweep writes regardless.  Fetching them
+// step by step would put an HBM round trip -- and, through the in-order vmcnt
+// counter, the completion of every earlier layer store -- on each step's
+// critical path.  Instead, once per BLK steps the whole wave moves the next
+// block's 16-byte pieces HBM -> LDS with LDS-DMA (global_load_lds_dwordx4: per-lane
+// source address, lane-linear destination, no VGPRs), one block ahead of use.
+// The DMA is issued from inline asm so that hipcc's waitcnt pass never sees a
+// pending load (it would drain the store queue with vmcnt(0) every step); the
+// one counted wait per block is written by hand.  The ghost of step g replays
+// record g - GOFF for every ghost lane alike, so the feed needs no lane state.
+// ---------------------------------------------------------------------------
+template <int S, int NL>
+struct GhostFeed {
+  using R_ = Rec<S, NL>;
+  static constexpr int W = 2 * S + 1, R = 64 / W;
+  static constexpr int NP = R_::NCH4 + (R_::TAIL ? 1 : 0);  // 16-byte pieces per (step, a)
+  static constexpr int BLK = S <= 1 ? 16 : (S == 2 ? 8 : 4); // steps per prefetch block
+  static constexpr int NPIECE = BLK * W * NP;
+  static constexpr int ROUNDS = (NPIECE + 63) / 64;
+  static constexpr int SLOTS = ROUNDS * 64;                  // pieces per ring half (lane-linear)
+  static constexpr int RING_DW = 2 * SLOTS * 4;              // two halves, dwords
+  static constexpr int MIN_GOFF = 2 * BLK + 8;               // records must be this old when read
+
+  // DMA the pieces of ghost steps [g0, g0+BLK) into the ring half at LDS byte address lds_base.
+  __device__ static __forceinline__ void issue(const int32_t* lay, int g0, int GOFF, int lane,
+                                               uint32_t lds_base) {
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+      const int q = min(r * 64 + lane, NPIECE - 1);
+      const int t = q / (W * NP), rem = q - t * (W * NP);
+      const int aa = rem / NP, c = rem - aa * NP;
+      const int64_t rec = max(g0 + t - GOFF, 0);
+      const int sl = (R - 1) * W + aa;
+      const int32_t* p = lay + rec * R_::RECDW +
+                         (c < R_::NCH4 ? c * 256 + sl * 4 : R_::NCH4 * 256 + sl * R_::TAIL);
+      const uint32_t dst = lds_base + r * 1024;  // wave-uniform; lane l lands at dst + 16*l
+      uint32_t keep;
+      asm volatile(
+          "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+          "global_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+          : "=&s"(keep)
+          : "v"(p), "s"(dst)
+          : "memory");
+    }
+  }
+  // All DMAs of the previous block were issued >= BLK steps (>= 63 vector-memory
+  // operations) ago; vmcnt is in-order, so any counted wait below 64 retires them.
+  __device__ static __forceinline__ void wait_block() { asm volatile("s_waitcnt vmcnt(40)" ::: "memory"); }
+
+  __device__ static __forceinline__ void fetch(int (&out)[R_::ND], const v4i* half, int t, int aa) {
+    const v4i* src = half + (t * W + aa) * NP;
+#pragma unroll
+    for (int c = 0; c < NP; ++c) {
+      const v4i v = src[c];
+      if (4 * c + 0 < R_::ND) out[4 * c + 0 < R_::ND ? 4 * c + 0 : 0] = v.x;
+      if (4 * c + 1 < R_::ND) out[4 * c + 1 < R_::ND ? 4 * c + 1 : 0] = v.y;
+      if (4 * c + 2 < R_::ND) out[4 * c + 2 < R_::ND ? 4 * c + 2 : 0] = v.z;
+      if (4 * c + 3 < R_::ND) out[4 * c + 3 < R_::ND ? 4 * c + 3 : 0] = v.w;
+    }
+  }
+};
+
 __device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
 // f_T for the three target halves; arguments are the values for source half Y, X, M.
 __device__ __forceinline__ int fM(int y, int x, int m) { return imax(imax(y, x), m); }
@@ -128,7 +194,9 @@ __global__ void __launch_bounds__(64) fill_affine_kernel(const DeviceBatch A) {
   const int gD = gamma + delta, gg = 2 * gamma, ggdd = 2 * gamma + 2 * delta, dd = 2 * delta;
 
   // ---- LDS carve-up
-  int32_t* xch = smem;                    // [NV][NCOL] exchange array
+  using GF = GhostFeed<S, 9>;
+  v4i* ring = reinterpret_cast<v4i*>(smem);     // ghost-row ring, two halves
+  int32_t* xch = smem + GF::RING_DW;            // [NV][NCOL] exchange array
   int32_t* s1 = xch + NV * NCOL;          // [k1*k1]
   int32_t* s2 = s1 + k1 * k1;             // [k2*k2]
   const int npad = (n + 3) & ~3, mpad = (m + 2 * PADB + 3) & ~3;
@@ -137,6 +205,7 @@ __global__ void __launch_bounds__(64) fill_affine_kernel(const DeviceBatch A) {
   uint8_t* sb = ca + npad;                                  // seq B codes, [j-1+PADB]
   uint8_t* cb = sb + mpad;                                  // cls B,       [l-1+PADB]
 
+  for (int t = L; t < GF::RING_DW; t += 64) smem[t] = SENT;
   for (int t = L; t < NV * NCOL; t += 64) xch[t] = SENT;
   for (int t = L; t < k1 * k1; t += 64) s1[t] = A.s1[t];
   for (int t = L; t < k2 * k2; t += 64) s2[t] = A.s2[t];
@@ -189,8 +258,20 @@ __global__ void __launch_bounds__(64) fill_affine_kernel(const DeviceBatch A) {
   }
 #pragma unroll
   for (int d = 0; d < ND; ++d) ghostM[d] = SENT;
+  const uint32_t ring_lds = __builtin_amdgcn_readfirstlane(
+      (uint32_t)(uintptr_t)(__attribute__((address_space(3))) int32_t*)smem);
 
   for (int g = 0; g < pd.G; ++g) {
+    // ---- 0. ghost feed: at a block boundary retire last block's DMAs and start the
+    //         next block's (before this step's stores); then pick this step's ghost
+    //         layers out of the ring
+    const int gt = g & (GF::BLK - 1), ghalf = (g / GF::BLK) & 1;
+    if (gt == 0) {
+      GF::wait_block();
+      GF::issue(lay, (g / GF::BLK + 1) * GF::BLK, GOFF, L, ring_lds + (ghalf ^ 1) * GF::SLOTS * 16);
+    }
+    GF::fetch(ghostM, ring + ghalf * GF::SLOTS, gt, aa);
+
     // ---- 1. exchange reads: what the three source lanes published last step
     int inA[W][4], inB[W][8], inC[W][8];
 #pragma unroll
@@ -344,28 +425,17 @@ __global__ void __launch_bounds__(64) fill_affine_kernel(const DeviceBatch A) {
       dC[1][bb] = inC[bb][1];
     }
 
-    // ---- 5. ghost row: fetch next step's layers (written GOFF steps ago by the
-    //         bottom row of the previous strip; issued before this step's stores)
-    if (ghost && live) {
-      int nj = jj + 1, nstrip = strip;
-      if (nj == P) { nj = 0; ++nstrip; }
-      if (nstrip >= 1 && nj >= 0 && nj <= m) {
-        const int32_t* src = lay + (int64_t)(g + 1 - GOFF) * RECDW;
-        const int sl = L + (R - 1) * W;
-#pragma unroll
-        for (int c = 0; c < NCH4; ++c) {
-          const v4i v = __builtin_nontemporal_load(reinterpret_cast<const v4i*>(src + c * 256 + sl * 4));
-          ghostM[4 * c] = v.x; ghostM[4 * c + 1] = v.y; ghostM[4 * c + 2] = v.z; ghostM[4 * c + 3] = v.w;
-        }
-#pragma unroll
-        for (int t = 0; t < TAIL; ++t)
-          ghostM[4 * NCH4 + t] = __builtin_nontemporal_load(src + NCH4 * 256 + sl * TAIL + t);
-      }
-    }
-
     // ---- 6. coalesced layer stores (pyx:504: M[state][idx] = ...)
-    if (tile_act && !ghost) {
-      int32_t* dst = lay + (int64_t)g * RECDW;
+#ifndef BIALIGN_EXP
+#define BIALIGN_EXP 0   // timing experiments only (tools/exp_build.sh): 1 = no stores, 2 = stores wrap in 1 MiB
+#endif
+    // Every lane owns a 16-byte slot in each chunk of the record, read back only for
+    // lattice points that exist; ghost lanes, lane 63 and out-of-lattice rows store
+    // don't-care values there so that the wave always writes whole 1 KiB runs (full
+    // HBM sectors, no masked partial writes).  Only fully idle steps skip the store.
+    if (BIALIGN_EXP != 1 && __builtin_amdgcn_ballot_w64(tile_act && !ghost) != 0) {
+      int32_t* dst = BIALIGN_EXP == 2 ? A.layers + ((int64_t)(blockIdx.x & 255) << 18) + (int64_t)(g & 31) * RECDW
+                                      : lay + (int64_t)g * RECDW;
 #pragma unroll
       for (int c = 0; c < NCH4; ++c) {
         v4i v;
@@ -544,7 +614,9 @@ __global__ void __launch_bounds__(64) fill_linear_kernel(const DeviceBatch A) {
   const int k1 = A.k1, k2 = A.k2;
   const int gD = gamma + delta, gg = 2 * gamma;
 
-  int32_t* xch = smem;
+  using GF = GhostFeed<S, 1>;
+  v4i* ring = reinterpret_cast<v4i*>(smem);
+  int32_t* xch = smem + GF::RING_DW;
   int32_t* s1 = xch + NV * NCOL;
   int32_t* s2 = s1 + k1 * k1;
   const int npad = (n + 3) & ~3, mpad = (m + 2 * PADB + 3) & ~3;
@@ -553,6 +625,7 @@ __global__ void __launch_bounds__(64) fill_linear_kernel(const DeviceBatch A) {
   uint8_t* sb = ca + npad;
   uint8_t* cb = sb + mpad;
 
+  for (int t = L; t < GF::RING_DW; t += 64) smem[t] = SENT;
   for (int t = L; t < NV * NCOL; t += 64) xch[t] = SENT;
   for (int t = L; t < k1 * k1; t += 64) s1[t] = A.s1[t];
   for (int t = L; t < k2 * k2; t += 64) s2[t] = A.s2[t];
@@ -594,8 +667,16 @@ __global__ void __launch_bounds__(64) fill_linear_kernel(const DeviceBatch A) {
   int ghostM[ND];
 #pragma unroll
   for (int bb = 0; bb < W; ++bb) lw1[bb] = lw2[bb] = lwp1[bb] = l11[bb] = selfM[bb] = ghostM[bb] = SENT;
+  const uint32_t ring_lds = __builtin_amdgcn_readfirstlane(
+      (uint32_t)(uintptr_t)(__attribute__((address_space(3))) int32_t*)smem);
 
   for (int g = 0; g < pd.G; ++g) {
+    const int gt = g & (GF::BLK - 1), ghalf = (g / GF::BLK) & 1;
+    if (gt == 0) {
+      GF::wait_block();
+      GF::issue(lay, (g / GF::BLK + 1) * GF::BLK, GOFF, L, ring_lds + (ghalf ^ 1) * GF::SLOTS * 16);
+    }
+    GF::fetch(ghostM, ring + ghalf * GF::SLOTS, gt, aa);
     int inLW[W], inLW1[W], inL1[W];
 #pragma unroll
     for (int bb = 0; bb < W; ++bb) {
@@ -653,23 +734,7 @@ __global__ void __launch_bounds__(64) fill_linear_kernel(const DeviceBatch A) {
       l11[bb] = inL1[bb];
     }
 
-    if (ghost && live) {
-      int nj = jj + 1, nstrip = strip;
-      if (nj == P) { nj = 0; ++nstrip; }
-      if (nstrip >= 1 && nj >= 0 && nj <= m) {
-        const int32_t* src = lay + (int64_t)(g + 1 - GOFF) * RECDW;
-        const int sl = L + (R - 1) * W;
-#pragma unroll
-        for (int c = 0; c < NCH4; ++c) {
-          const v4i v = __builtin_nontemporal_load(reinterpret_cast<const v4i*>(src + c * 256 + sl * 4));
-          ghostM[4 * c] = v.x; ghostM[4 * c + 1] = v.y; ghostM[4 * c + 2] = v.z; ghostM[4 * c + 3] = v.w;
-        }
-#pragma unroll
-        for (int t = 0; t < TAIL; ++t)
-          ghostM[4 * NCH4 + t] = __builtin_nontemporal_load(src + NCH4 * 256 + sl * TAIL + t);
-      }
-    }
-    if (tile_act && !ghost) {
+    if (__builtin_amdgcn_ballot_w64(tile_act && !ghost) != 0) {  // whole-wave stores, see the affine kernel
       int32_t* dst = lay + (int64_t)g * RECDW;
 #pragma unroll
       for (int c = 0; c < NCH4; ++c) {
