@@ -135,17 +135,23 @@ size_t lds_need(int S, int NL, int k1, int k2, int n, int m) {
   return (ring_dw + nv * NCOL + (size_t)k1 * k1 + (size_t)k2 * k2) * 4 + 2 * npad + 2 * mpad;
 }
 
-template <int S>
-int launch_fill_affine(const bialign_batch* b, const DeviceBatch& v, int first, int count) {
+template <int S, bool BETA_NONPOS>
+int launch_fill_affine_b(const bialign_batch* b, const DeviceBatch& v, int first, int count) {
   DeviceBatch w = v;
   w.order = v.order + first;
-  auto kern = fill_affine_kernel<S>;
+  auto kern = fill_affine_kernel<S, BETA_NONPOS>;
   if (b->lds_bytes > 64 * 1024)
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_bytes));
   hipLaunchKernelGGL(kern, dim3(count), dim3(64), b->lds_bytes, b->eng->stream, w);
   HIP_TRY(hipGetLastError());
   return BIALIGN_OK;
+}
+
+template <int S>
+int launch_fill_affine(const bialign_batch* b, const DeviceBatch& v, int first, int count) {
+  return b->prm.gap_opening_cost <= 0 ? launch_fill_affine_b<S, true>(b, v, first, count)
+                                      : launch_fill_affine_b<S, false>(b, v, first, count);
 }
 
 template <int S>

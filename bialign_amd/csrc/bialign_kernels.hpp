@@ -33,6 +33,13 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#ifndef BIALIGN_EXP
+// timing experiments only (tools/exp_build.sh; results are wrong by construction):
+// 1 = no layer stores, 2 = stores wrap inside 1 MiB per wave, 3 = never take the
+// interior step variant, 4 = always take it
+#define BIALIGN_EXP 0
+#endif
+
 namespace bialign {
 
 constexpr int32_t NEG = -(1 << 30);                 // reference -infinity
@@ -175,7 +182,33 @@ __device__ __forceinline__ int fY(int y, int x, int m, int beta) { return imax(y
 // ---------------------------------------------------------------------------
 // Affine fill (pyx:474-509).  One wave per pair.
 // ---------------------------------------------------------------------------
-template <int S>
+// Can target state (hU,hV) at band column bb end up with no guard-valid case for
+// some band row a when all four lattice coordinates are >= 1?  (Then only the
+// band decides validity and the answer is static per (state, bb).)
+template <int W>
+__host__ __device__ constexpr bool can_be_empty(int hU, int hV, int bb) {
+  const int u0 = hU >= 1, u1 = hU != 1, v0 = hV >= 1, v1 = hV != 1;
+  for (int aa = 0; aa < W; ++aa) {
+    const int a1 = aa + u0 - v0, b1 = bb + u1 - v1;  // group 1, offset (U,V)
+    const int a2 = aa - v0, b2 = bb - v1;            // group 2, offset (0,0,V)
+    const int a3 = aa + u0, b3 = bb + u1;            // group 3, offset (U,0,0)
+    const bool g1 = a1 >= 0 && a1 < W && b1 >= 0 && b1 < W;
+    const bool g2 = a2 >= 0 && a2 < W && b2 >= 0 && b2 < W;
+    const bool g3 = a3 >= 0 && a3 < W && b3 >= 0 && b3 < W;
+    if (!g1 && !g2 && !g3) return true;
+  }
+  return false;
+}
+
+template <bool V>
+struct BoolTag {
+  static constexpr bool value = V;
+};
+
+// BETA_NONPOS: gap_opening_cost <= 0 (every practical parameter set).  Then
+// open(h,T) + v[h] <= v[T] + ... lets f_X, f_Y reuse f_M's max3:
+//   f_X(v) = max(v[X], beta + max3(v))     (exact for beta <= 0 only)
+template <int S, bool BETA_NONPOS>
 __global__ void __launch_bounds__(64) fill_affine_kernel(const DeviceBatch A) {
   using G_ = Geo<S>;
   using R_ = Rec<S, 9>;
@@ -197,8 +230,8 @@ __global__ void __launch_bounds__(64) fill_affine_kernel(const DeviceBatch A) {
   using GF = GhostFeed<S, 9>;
   v4i* ring = reinterpret_cast<v4i*>(smem);     // ghost-row ring, two halves
   int32_t* xch = smem + GF::RING_DW;            // [NV][NCOL] exchange array
-  int32_t* s1 = xch + NV * NCOL;          // [k1*k1]
-  int32_t* s2 = s1 + k1 * k1;             // [k2*k2]
+  int32_t* s1 = xch + NV * NCOL;                // [k1*k1]
+  int32_t* s2 = s1 + k1 * k1;                   // [k2*k2]
   const int npad = (n + 3) & ~3, mpad = (m + 2 * PADB + 3) & ~3;
   uint8_t* sa = reinterpret_cast<uint8_t*>(s2 + k2 * k2);  // seq A codes, [i-1]
   uint8_t* ca = sa + npad;                                  // cls A,       [k-1]
@@ -261,7 +294,13 @@ __global__ void __launch_bounds__(64) fill_affine_kernel(const DeviceBatch A) {
   const uint32_t ring_lds = __builtin_amdgcn_readfirstlane(
       (uint32_t)(uintptr_t)(__attribute__((address_space(3))) int32_t*)smem);
 
-  for (int g = 0; g < pd.G; ++g) {
+  // One step of the sweep.  INTERIOR steps (every lane's lattice points have all
+  // four coordinates >= 1 and lie inside the molecule columns; ~90 % of the
+  // steps) know that only the band can invalidate a case, so the "no valid case"
+  // test runs for the few (state, b) pairs where that is possible and the
+  // out-of-lattice bookkeeping disappears; boundary steps take the general form.
+  auto step = [&](auto interior_tag, int g) __attribute__((always_inline)) {
+    constexpr bool INTERIOR = decltype(interior_tag)::value;
     // ---- 0. ghost feed: at a block boundary retire last block's DMAs and start the
     //         next block's (before this step's stores); then pick this step's ghost
     //         layers out of the ring
@@ -285,14 +324,14 @@ __global__ void __launch_bounds__(64) fill_affine_kernel(const DeviceBatch A) {
     }
 
     // ---- 2. score inputs of this column (pyx:260-261; LOOKUP form)
-    const int jc = min(max(jj, 0), m + 1);
+    const int jc = INTERIOR ? jj : min(max(jj, 0), m + 1);
     const int mu1 = s1[s1row + sb[jc - 1 + PADB]];
     int mu2[W];
 #pragma unroll
     for (int bb = 0; bb < W; ++bb) mu2[bb] = s2[s2row + cb[jc + bb]];  // l-1+PADB = jc+bb
 
-    const bool tile_act = act_row && jj >= 0 && jj <= m;
-    const bool is_origin = tile_act && i == 0 && jj == 0 && aa == S;
+    const bool tile_act = INTERIOR ? true : (act_row && jj >= 0 && jj <= m);
+    const bool is_origin = INTERIOR ? false : (tile_act && i == 0 && jj == 0 && aa == S);
     const int c3M = mu1 + dd, c_Mg = mu1 + gD;
 
     // ---- 3. the W lattice points of this (i, j, a)
@@ -301,7 +340,7 @@ __global__ void __launch_bounds__(64) fill_affine_kernel(const DeviceBatch A) {
 #pragma unroll
     for (int bb = 0; bb < W; ++bb) {
       const int l = jj + bb - S;
-      const bool act = tile_act && l >= 0 && l <= m;
+      const bool act = INTERIOR ? true : (tile_act && l >= 0 && l <= m);
       const int mu2v = mu2[bb];
       const int c_MM = mu1 + mu2v, c_gM = mu2v + gD, c2M = mu2v + dd;
 
@@ -353,15 +392,24 @@ __global__ void __launch_bounds__(64) fill_affine_kernel(const DeviceBatch A) {
 
       // finalise: ghost rows take the stored layers; "no valid case" -> -2^30
       // (pyx:299-303); points outside the lattice carry the sentinel.
-      const int low = act ? NEG : SENT;
       int M[9];
+      if (INTERIOR) {
 #pragma unroll
-      for (int q = 0; q < 9; ++q) {
-        const int tv = ghost ? ghostM[bb * 9 + q] : T[q];
-        const bool bad = (tv < THRESH) | !act;
-        M[q] = bad ? low : tv;
+        for (int q = 0; q < 9; ++q) {
+          int tv = ghost ? ghostM[bb * 9 + q] : T[q];
+          if (can_be_empty<W>(q / 3, q % 3, bb)) tv = tv < THRESH ? NEG : tv;
+          M[q] = tv;
+        }
+      } else {
+        const int low = act ? NEG : SENT;
+#pragma unroll
+        for (int q = 0; q < 9; ++q) {
+          const int tv = ghost ? ghostM[bb * 9 + q] : T[q];
+          const bool bad = (tv < THRESH) | !act;
+          M[q] = bad ? low : tv;
+        }
+        if (bb == S) M[8] = is_origin ? 0 : M[8];  // pyx:483-485
       }
-      if (bb == S) M[8] = is_origin ? 0 : M[8];  // pyx:483-485
 #pragma unroll
       for (int q = 0; q < 9; ++q) outv[bb * 9 + q] = M[q];
 
@@ -369,18 +417,32 @@ __global__ void __launch_bounds__(64) fill_affine_kernel(const DeviceBatch A) {
       int H2[3][3], H3[3][3], Gd[3][3];
 #pragma unroll
       for (int u = 0; u < 3; ++u) {
-        H2[u][0] = fY(M[3 * u], M[3 * u + 1], M[3 * u + 2], beta);
-        H2[u][1] = fX(M[3 * u], M[3 * u + 1], M[3 * u + 2], beta);
         H2[u][2] = fM(M[3 * u], M[3 * u + 1], M[3 * u + 2]);
+        if (BETA_NONPOS) {
+          const int bm = beta + H2[u][2];
+          H2[u][0] = imax(M[3 * u], bm);
+          H2[u][1] = imax(M[3 * u + 1], bm);
+        } else {
+          H2[u][0] = fY(M[3 * u], M[3 * u + 1], M[3 * u + 2], beta);
+          H2[u][1] = fX(M[3 * u], M[3 * u + 1], M[3 * u + 2], beta);
+        }
       }
 #pragma unroll
       for (int v = 0; v < 3; ++v) {
-        H3[0][v] = fY(M[v], M[3 + v], M[6 + v], beta);
-        H3[1][v] = fX(M[v], M[3 + v], M[6 + v], beta);
         H3[2][v] = fM(M[v], M[3 + v], M[6 + v]);
-        Gd[0][v] = fY(H2[0][v], H2[1][v], H2[2][v], beta);
-        Gd[1][v] = fX(H2[0][v], H2[1][v], H2[2][v], beta);
         Gd[2][v] = fM(H2[0][v], H2[1][v], H2[2][v]);
+        if (BETA_NONPOS) {
+          const int bm3 = beta + H3[2][v], bmg = beta + Gd[2][v];
+          H3[0][v] = imax(M[v], bm3);
+          H3[1][v] = imax(M[3 + v], bm3);
+          Gd[0][v] = imax(H2[0][v], bmg);
+          Gd[1][v] = imax(H2[1][v], bmg);
+        } else {
+          H3[0][v] = fY(M[v], M[3 + v], M[6 + v], beta);
+          H3[1][v] = fX(M[v], M[3 + v], M[6 + v], beta);
+          Gd[0][v] = fY(H2[0][v], H2[1][v], H2[2][v], beta);
+          Gd[1][v] = fX(H2[0][v], H2[1][v], H2[2][v], beta);
+        }
       }
       // publish (all reads of this step were issued above, LDS keeps order)
       int32_t* row = xch + (bb * 20) * NCOL + L;
@@ -425,15 +487,12 @@ __global__ void __launch_bounds__(64) fill_affine_kernel(const DeviceBatch A) {
       dC[1][bb] = inC[bb][1];
     }
 
-    // ---- 6. coalesced layer stores (pyx:504: M[state][idx] = ...)
-#ifndef BIALIGN_EXP
-#define BIALIGN_EXP 0   // timing experiments only (tools/exp_build.sh): 1 = no stores, 2 = stores wrap in 1 MiB
-#endif
+    // ---- 5. coalesced layer stores (pyx:504: M[state][idx] = ...)
     // Every lane owns a 16-byte slot in each chunk of the record, read back only for
     // lattice points that exist; ghost lanes, lane 63 and out-of-lattice rows store
     // don't-care values there so that the wave always writes whole 1 KiB runs (full
     // HBM sectors, no masked partial writes).  Only fully idle steps skip the store.
-    if (BIALIGN_EXP != 1 && __builtin_amdgcn_ballot_w64(tile_act && !ghost) != 0) {
+    if (BIALIGN_EXP != 1 && (INTERIOR || __builtin_amdgcn_ballot_w64(tile_act && !ghost) != 0)) {
       int32_t* dst = BIALIGN_EXP == 2 ? A.layers + ((int64_t)(blockIdx.x & 255) << 18) + (int64_t)(g & 31) * RECDW
                                       : lay + (int64_t)g * RECDW;
 #pragma unroll
@@ -446,12 +505,30 @@ __global__ void __launch_bounds__(64) fill_affine_kernel(const DeviceBatch A) {
       for (int t = 0; t < TAIL; ++t) dst[NCH4 * 256 + L * TAIL + t] = outv[4 * NCH4 + t];
     }
 
-    // ---- 7. advance
+    // ---- 6. advance
     ++jj;
     if (jj == P) {
       jj = 0;
       ++strip;
       set_row(strip);
+    }
+  };
+
+  // Two separate loops (not one loop with a branch inside): each keeps its loop-carried
+  // registers where it likes; values only move at the rare hand-overs between runs.
+  auto all_interior = [&]() __attribute__((always_inline)) {
+    const bool lane_interior = !live || (jj >= S + 1 && jj <= m && i >= S + 1);
+    return __builtin_amdgcn_ballot_w64(lane_interior) == ~0ull;
+  };
+  int g = 0;
+  while (g < pd.G) {
+    while (g < pd.G && (BIALIGN_EXP == 3 || (BIALIGN_EXP != 4 && !all_interior()))) {
+      step(BoolTag<false>{}, g);
+      ++g;
+    }
+    while (g < pd.G && BIALIGN_EXP != 3 && (BIALIGN_EXP == 4 || all_interior())) {
+      step(BoolTag<true>{}, g);
+      ++g;
     }
   }
 }
