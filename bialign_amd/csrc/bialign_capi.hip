@@ -63,10 +63,20 @@ struct DevBuf {
   }
 };
 
+// GhostFeed<S,.>::BLK
+int ghost_blk(int S) {
+#ifdef BIALIGN_BLK_OVERRIDE
+  (void)S;
+  return BIALIGN_BLK_OVERRIDE;
+#else
+  return S <= 2 ? 8 : 4;
+#endif
+}
+
 // Sweep geometry of one pair (mirrors the kernel's Geo<S>): strips, period, steps.
 void sweep_geometry(int n, int m, int S, int* NS, int* P, int* G) {
   const int W = 2 * S + 1, R = 64 / W, RR = R - 1;
-  const int min_goff = 2 * (S <= 1 ? 16 : (S == 2 ? 8 : 4)) + 8;  // GhostFeed<S,.>::MIN_GOFF
+  const int min_goff = 2 * ghost_blk(S) + 8;  // GhostFeed<S,.>::MIN_GOFF
   *NS = (n + 1 + RR - 1) / RR;
   // one idle column between strips (P >= m+2) and ghost records old enough to prefetch
   *P = std::max(m + 2, 2 * (R - 1) + min_goff);
@@ -130,7 +140,7 @@ size_t lds_need(int S, int NL, int k1, int k2, int n, int m) {
   const int W = 2 * S + 1, PADB = S + 1;
   const size_t nv = (NL == 9 ? 20 : 1) * W;
   const size_t npad = (n + 3) & ~3, mpad = (m + 2 * PADB + 3) & ~3;
-  const int nd = NL * W, np = nd / 4 + (nd % 4 ? 1 : 0), blk = S <= 1 ? 16 : (S == 2 ? 8 : 4);
+  const int nd = NL * W, np = nd / 4 + (nd % 4 ? 1 : 0), blk = ghost_blk(S);
   const size_t ring_dw = 2 * (((size_t)blk * W * np + 63) / 64 * 64) * 4;  // GhostFeed<S,NL>::RING_DW
   return (ring_dw + nv * NCOL + (size_t)k1 * k1 + (size_t)k2 * k2) * 4 + 2 * npad + 2 * mpad;
 }

@@ -127,7 +127,11 @@ struct GhostFeed {
   using R_ = Rec<S, NL>;
   static constexpr int W = 2 * S + 1, R = 64 / W;
   static constexpr int NP = R_::NCH4 + (R_::TAIL ? 1 : 0);  // 16-byte pieces per (step, a)
-  static constexpr int BLK = S <= 1 ? 16 : (S == 2 ? 8 : 4); // steps per prefetch block
+#ifdef BIALIGN_BLK_OVERRIDE
+  static constexpr int BLK = BIALIGN_BLK_OVERRIDE;
+#else
+  static constexpr int BLK = S <= 2 ? 8 : 4;  // steps per prefetch block
+#endif
   static constexpr int NPIECE = BLK * W * NP;
   static constexpr int ROUNDS = (NPIECE + 63) / 64;
   static constexpr int SLOTS = ROUNDS * 64;                  // pieces per ring half (lane-linear)
