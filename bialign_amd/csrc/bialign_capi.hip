@@ -138,7 +138,7 @@ namespace {
 
 size_t lds_need(int S, int NL, int k1, int k2, int n, int m) {
   const int W = 2 * S + 1, PADB = S + 1;
-  const size_t nv = (NL == 9 ? 20 : 1) * W;
+  const size_t nv = (NL == 9 ? 12 : 1) * W;
   const size_t npad = (n + 3) & ~3, mpad = (m + 2 * PADB + 3) & ~3;
   const int nd = NL * W, np = nd / 4 + (nd % 4 ? 1 : 0), blk = ghost_blk(S);
   const size_t ring_dw = 2 * (((size_t)blk * W * np + 63) / 64 * 64) * 4;  // GhostFeed<S,NL>::RING_DW

@@ -12,7 +12,8 @@
 // With this skew every predecessor named by the reference's case generator
 // (pyx:255-296) was computed 1, 2 or 3 steps earlier by lane L-1, L-W+1, L-W or
 // by the lane itself.  Values cross lanes through a per-wave LDS exchange array
-// (written at the end of a step, read at the start of the next one); values
+// (written at the end of a step, read at the start of the next one; lane L-1's
+// values travel by a DPP wave shift instead); values
 // needed 2 or 3 steps later wait in registers.  Nothing crosses waves, so the
 // sweep needs no barrier.
 //
@@ -217,7 +218,8 @@ __global__ void __launch_bounds__(64) fill_affine_kernel(const DeviceBatch A) {
   using G_ = Geo<S>;
   using R_ = Rec<S, 9>;
   constexpr int W = G_::W, R = G_::R, RR = G_::RR, PADB = G_::PADB;
-  constexpr int NV = 20 * W, ND = R_::ND, NCH4 = R_::NCH4, TAIL = R_::TAIL, RECDW = R_::RECDW;
+  constexpr int XR = 12;  // exchange rows per point that go through LDS
+  constexpr int NV = XR * W, ND = R_::ND, NCH4 = R_::NCH4, TAIL = R_::TAIL, RECDW = R_::RECDW;
   extern __shared__ __align__(16) int32_t smem[];
 
   const PairDesc pd = A.pairs[A.order[blockIdx.x]];
@@ -261,7 +263,7 @@ __global__ void __launch_bounds__(64) fill_affine_kernel(const DeviceBatch A) {
   // ---- per-lane constants
   const int colLW = (live && il >= 1) ? L - W : 64;                    // (i-1, a)
   const int colLW1 = (live && il >= 1 && aa < W - 1) ? L - W + 1 : 64; // (i-1, a+1)
-  const int colL1 = (live && il >= 1 && aa > 0) ? L - 1 : 64;          // (i,   a-1)
+  const bool a_first = (aa == 0);  // no (i, a-1) inside the band: lane L-1 is another row
   const int GOFF = P - 2 * (R - 1);  // steps between a bottom row and its ghost copy
   int32_t* const lay = A.layers + pd.layer_off;
 
@@ -285,6 +287,7 @@ __global__ void __launch_bounds__(64) fill_affine_kernel(const DeviceBatch A) {
   int dB[4][W];              // GMY, H3M[0..2] from (i-1,a+1): age 2
   int dC[2][W];              // GYM, GYX from (i,a-1): age 2
   int selfv[4][W];           // GYY, H3Y[0..2] of this lane's previous column
+  int pubC[W][8];            // GYM, GYX, H2M[0..2], H2X[0..2] of the previous column, for lane L+1
   int ghostM[ND];            // ghost row: the nine layers of its W points
 #pragma unroll
   for (int bb = 0; bb < W; ++bb) {
@@ -292,6 +295,8 @@ __global__ void __launch_bounds__(64) fill_affine_kernel(const DeviceBatch A) {
     dAx[0][bb] = dAx[1][bb] = dC[0][bb] = dC[1][bb] = SENT;
 #pragma unroll
     for (int x = 0; x < 4; ++x) dB[x][bb] = selfv[x][bb] = SENT;
+#pragma unroll
+    for (int x = 0; x < 8; ++x) pubC[bb][x] = SENT;
   }
 #pragma unroll
   for (int d = 0; d < ND; ++d) ghostM[d] = SENT;
@@ -320,11 +325,16 @@ __global__ void __launch_bounds__(64) fill_affine_kernel(const DeviceBatch A) {
 #pragma unroll
     for (int bb = 0; bb < W; ++bb) {
 #pragma unroll
-      for (int x = 0; x < 4; ++x) inA[bb][x] = xch[(bb * 20 + x) * NCOL + colLW];
+      for (int x = 0; x < 4; ++x) inA[bb][x] = xch[(bb * XR + x) * NCOL + colLW];
 #pragma unroll
-      for (int x = 0; x < 8; ++x) inB[bb][x] = xch[(bb * 20 + 4 + x) * NCOL + colLW1];
+      for (int x = 0; x < 8; ++x) inB[bb][x] = xch[(bb * XR + 4 + x) * NCOL + colLW1];
+      // lane L-1 = (i, a-1) hands its values over in registers: one DPP wave shift,
+      // and the sentinel where a-1 leaves the band
 #pragma unroll
-      for (int x = 0; x < 8; ++x) inC[bb][x] = xch[(bb * 20 + 12 + x) * NCOL + colL1];
+      for (int x = 0; x < 8; ++x) {
+        const int nb = __builtin_amdgcn_update_dpp(SENT, pubC[bb][x], 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+        inC[bb][x] = a_first ? SENT : nb;
+      }
     }
 
     // ---- 2. score inputs of this column (pyx:260-261; LOOKUP form)
@@ -449,7 +459,7 @@ __global__ void __launch_bounds__(64) fill_affine_kernel(const DeviceBatch A) {
         }
       }
       // publish (all reads of this step were issued above, LDS keeps order)
-      int32_t* row = xch + (bb * 20) * NCOL + L;
+      int32_t* row = xch + (bb * XR) * NCOL + L;
       row[0 * NCOL] = Gd[2][2];
       row[1 * NCOL] = Gd[2][1];
       row[2 * NCOL] = Gd[1][2];
@@ -461,12 +471,12 @@ __global__ void __launch_bounds__(64) fill_affine_kernel(const DeviceBatch A) {
         row[(6 + v) * NCOL] = H3[2][v];
         row[(9 + v) * NCOL] = H3[1][v];
       }
-      row[12 * NCOL] = Gd[0][2];
-      row[13 * NCOL] = Gd[0][1];
+      pubC[bb][0] = Gd[0][2];
+      pubC[bb][1] = Gd[0][1];
 #pragma unroll
       for (int u = 0; u < 3; ++u) {
-        row[(14 + u) * NCOL] = H2[u][2];
-        row[(17 + u) * NCOL] = H2[u][1];
+        pubC[bb][2 + u] = H2[u][2];
+        pubC[bb][5 + u] = H2[u][1];
       }
       selfv[0][bb] = Gd[0][0];
 #pragma unroll
