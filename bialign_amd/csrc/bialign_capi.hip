@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <numeric>
@@ -109,9 +110,9 @@ struct bialign_batch {
   std::vector<int32_t> order;       // chunk-by-chunk launch order
   std::vector<int> chunk_begin;     // index into order, size nchunks+1
   int64_t cells = 0, trace_bytes = 0, max_chunk_dwords = 0;
-  size_t lds_bytes = 0;
+  size_t lds_bytes = 0, lds_bytes_team = 0;  // dynamic LDS per workgroup: one wave / two waves per pair
   DevBuf<PairDesc> d_pairs;
-  DevBuf<int32_t> d_order, d_s1, d_s2, d_layers, d_scores, d_tlen, d_complete;
+  DevBuf<int32_t> d_order, d_s1, d_s2, d_layers, d_scores, d_tlen, d_complete, d_err;
   DevBuf<uint8_t> d_seq_a, d_cls_a, d_seq_b, d_cls_b, d_trace;
   int k1 = 0, k2 = 0;
   bialign_timing timing{};
@@ -130,38 +131,61 @@ struct bialign_batch {
     v.trace = d_trace.p;
     v.trace_len = d_tlen.p;
     v.complete = d_complete.p;
+    v.errflag = d_err.p;
     return v;
   }
 };
 
 namespace {
 
-size_t lds_need(int S, int NL, int k1, int k2, int n, int m) {
+size_t lds_need(int S, int NL, int team, int k1, int k2, int n, int m) {
   const int W = 2 * S + 1, PADB = S + 1;
   const size_t nv = (NL == 9 ? 12 : 1) * W;
   const size_t npad = (n + 3) & ~3, mpad = (m + 2 * PADB + 3) & ~3;
   const int nd = NL * W, np = nd / 4 + (nd % 4 ? 1 : 0), blk = ghost_blk(S);
   const size_t ring_dw = 2 * (((size_t)blk * W * np + 63) / 64 * 64) * 4;  // GhostFeed<S,NL>::RING_DW
-  return (ring_dw + nv * NCOL + (size_t)k1 * k1 + (size_t)k2 * k2) * 4 + 2 * npad + 2 * mpad;
+  const size_t shared_dw = (NL == 9 ? 4 : 0) + (size_t)k1 * k1 + (size_t)k2 * k2;
+  return (team * (ring_dw + nv * NCOL) + shared_dw) * 4 + 2 * npad + 2 * mpad;
 }
 
-template <int S, bool BETA_NONPOS>
-int launch_fill_affine_b(const bialign_batch* b, const DeviceBatch& v, int first, int count) {
+template <int S, bool BETA_NONPOS, int T>
+int launch_fill_affine_t(const bialign_batch* b, const DeviceBatch& v, int first, int count) {
   DeviceBatch w = v;
   w.order = v.order + first;
-  auto kern = fill_affine_kernel<S, BETA_NONPOS>;
-  if (b->lds_bytes > 64 * 1024)
+  auto kern = fill_affine_kernel<S, BETA_NONPOS, T>;
+  const size_t lds = T == 1 ? b->lds_bytes : b->lds_bytes_team;
+  if (lds > 64 * 1024)
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_bytes));
-  hipLaunchKernelGGL(kern, dim3(count), dim3(64), b->lds_bytes, b->eng->stream, w);
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(kern, dim3(count), dim3(64 * T), lds, b->eng->stream, w);
   HIP_TRY(hipGetLastError());
   return BIALIGN_OK;
 }
 
+// Waves per pair.  Two waves per pair double the waves per SIMD when a launch has fewer
+// pairs than the chip has wave slots worth filling (256 CUs x 4 SIMDs x 2); they need
+// P >= 256 so that the two waves never wait on each other (see the kernel's header).
+int team_size(const bialign_batch* b, int first, int count) {
+  const int W = 2 * b->S + 1, R = 64 / W;
+  // wave w>=1 trails wave w-1 by 2(R-1)+2*BLK+8 steps and wave 0 leads wave 1 by at most
+  // P minus that: both hold without mutual waiting only if P is at least twice the lag
+  const int p_min = std::max(256, 2 * (2 * (R - 1) + 2 * ghost_blk(b->S) + 16));
+  bool safe = b->affine && b->S <= 1 && b->lds_bytes_team <= 64 * 1024;
+  for (int t = first; safe && t < first + count; ++t)
+    safe = b->pairs[b->order[t]].P >= p_min && b->pairs[b->order[t]].NS >= 4;
+  if (!safe) return 1;
+  if (const char* e = getenv("BIALIGN_TEAM")) return atoi(e) == 2 ? 2 : 1;  // experiments / tests
+  return (count <= 1536 && b->lds_bytes_team <= 40 * 1024) ? 2 : 1;
+}
+
 template <int S>
 int launch_fill_affine(const bialign_batch* b, const DeviceBatch& v, int first, int count) {
-  return b->prm.gap_opening_cost <= 0 ? launch_fill_affine_b<S, true>(b, v, first, count)
-                                      : launch_fill_affine_b<S, false>(b, v, first, count);
+  const bool np = b->prm.gap_opening_cost <= 0;
+  if (S <= 1 && team_size(b, first, count) == 2)
+    return np ? launch_fill_affine_t<S, true, 2>(b, v, first, count)
+              : launch_fill_affine_t<S, false, 2>(b, v, first, count);
+  return np ? launch_fill_affine_t<S, true, 1>(b, v, first, count)
+            : launch_fill_affine_t<S, false, 1>(b, v, first, count);
 }
 
 template <int S>
@@ -376,7 +400,8 @@ int bialign_batch_create(bialign_engine* eng, const bialign_params* prm, const b
     b->cells += cells_of(n, m, S);
     tot_a = std::max<int64_t>(tot_a, pr->off_a[p] + n);
     tot_b = std::max<int64_t>(tot_b, pr->off_b[p] + m);
-    b->lds_bytes = std::max(b->lds_bytes, lds_need(S, b->NL, sc->k1, sc->k2, n, m));
+    b->lds_bytes = std::max(b->lds_bytes, lds_need(S, b->NL, 1, sc->k1, sc->k2, n, m));
+    b->lds_bytes_team = std::max(b->lds_bytes_team, lds_need(S, b->NL, 2, sc->k1, sc->k2, n, m));
   }
   if (b->lds_bytes > 160 * 1024)
     return fail(BIALIGN_E_UNSUPPORTED, "molecules too long for the LDS staging (%zu bytes needed)", b->lds_bytes);
@@ -422,6 +447,8 @@ int bialign_batch_create(bialign_engine* eng, const bialign_params* prm, const b
   HIP_TRY(b->d_scores.alloc(pr->npairs));
   HIP_TRY(b->d_tlen.alloc(pr->npairs));
   HIP_TRY(b->d_complete.alloc(pr->npairs));
+  HIP_TRY(b->d_err.alloc(1));
+  HIP_TRY(hipMemsetAsync(b->d_err.p, 0, sizeof(int32_t), st));
   HIP_TRY(b->d_trace.alloc(b->trace_bytes));
   HIP_TRY(hipMemsetAsync(b->d_tlen.p, 0, sizeof(int32_t) * pr->npairs, st));
   HIP_TRY(hipMemsetAsync(b->d_complete.p, 0, sizeof(int32_t) * pr->npairs, st));
@@ -477,6 +504,9 @@ int bialign_batch_run(bialign_batch* b, uint32_t flags) {
     b->timing.traceback_launches += 1;
   }
   HIP_TRY(hipStreamSynchronize(st));
+  int32_t err = 0;
+  HIP_TRY(hipMemcpy(&err, b->d_err.p, sizeof err, hipMemcpyDeviceToHost));
+  if (err) return fail(BIALIGN_E_DEVICE, "fill kernel: team hand-off timed out (device error flag %d)", err);
   b->ran = true;
   b->ran_trace = do_trace;
   return BIALIGN_OK;

@@ -70,6 +70,7 @@ struct DeviceBatch {
   uint8_t* trace;       // trace buffer
   int32_t* trace_len;   // [npairs]
   int32_t* complete;    // [npairs]
+  int32_t* errflag;     // [1] sticky device-side error (team protocol timeout)
 };
 
 template <int S>
@@ -139,23 +140,32 @@ struct GhostFeed {
   static constexpr int RING_DW = 2 * SLOTS * 4;              // two halves, dwords
   static constexpr int MIN_GOFF = 2 * BLK + 8;               // records must be this old when read
 
-  // DMA the pieces of ghost steps [g0, g0+BLK) into the ring half at LDS byte address lds_base.
-  __device__ static __forceinline__ void issue(const int32_t* lay, int g0, int GOFF, int lane,
+  // DMA the pieces of ghost steps [h0, h0+BLK) of this wave's sweep into the ring half
+  // at LDS byte address lds_base.  A ghost lane (0,aa) at local step h sits in local
+  // strip q = floor((h-aa)/P) and replays record  h + (q(T-1)+w)P - GOFF  (T waves per
+  // pair, this one sweeps strips w, w+T, ...; T=1,w=0 gives h - GOFF).  blk_q / blk_rem
+  // = h0 div / mod P, kept incrementally by the caller.
+  template <int T>
+  __device__ static __forceinline__ void issue(const int32_t* lay, int h0, int blk_q, int blk_rem,
+                                               int P, int w, int GOFF, int rec_last, int lane,
                                                uint32_t lds_base) {
 #pragma unroll
     for (int r = 0; r < ROUNDS; ++r) {
       const int q = min(r * 64 + lane, NPIECE - 1);
       const int t = q / (W * NP), rem = q - t * (W * NP);
       const int aa = rem / NP, c = rem - aa * NP;
-      const int64_t rec = max(g0 + t - GOFF, 0);
+      const int xr = blk_rem + t - aa;
+      const int ql = blk_q + (xr >= P ? 1 : 0) - (xr < 0 ? 1 : 0);
+      const int rec = min(max(h0 + t - GOFF + (ql * (T - 1) + w) * P, 0), rec_last);
       const int sl = (R - 1) * W + aa;
-      const int32_t* p = lay + rec * R_::RECDW +
+      const int32_t* p = lay + (int64_t)rec * R_::RECDW +
                          (c < R_::NCH4 ? c * 256 + sl * 4 : R_::NCH4 * 256 + sl * R_::TAIL);
       const uint32_t dst = lds_base + r * 1024;  // wave-uniform; lane l lands at dst + 16*l
       uint32_t keep;
+      // sc1: served by L2, never by this CU's L1 (the records may come from the partner wave)
       asm volatile(
           "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
-          "global_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+          "global_load_lds_dwordx4 %1, off sc1\n\ts_mov_b32 m0, %0"
           : "=&s"(keep)
           : "v"(p), "s"(dst)
           : "memory");
@@ -213,8 +223,16 @@ struct BoolTag {
 // BETA_NONPOS: gap_opening_cost <= 0 (every practical parameter set).  Then
 // open(h,T) + v[h] <= v[T] + ... lets f_X, f_Y reuse f_M's max3:
 //   f_X(v) = max(v[X], beta + max3(v))     (exact for beta <= 0 only)
-template <int S, bool BETA_NONPOS>
-__global__ void __launch_bounds__(64) fill_affine_kernel(const DeviceBatch A) {
+//
+// TEAM = T waves per pair (one workgroup).  Wave w sweeps strips w, w+T, w+2T, ...
+// with the same record layout as a single wave would produce; the only coupling
+// is the ghost feed, which now replays records the partner wave wrote.  Each wave
+// publishes in an LDS word how many of its steps have their stores acknowledged;
+// a wave checks the partner's word once per ghost block before prefetching.  Wave
+// w>=1 therefore trails wave w-1 by >= 2(R-1)+2*BLK+8 steps, wave 0 may lead wave
+// T-1 by at most P-(that): the host picks T=2 only for P >= 256.
+template <int S, bool BETA_NONPOS, int T>
+__global__ void __launch_bounds__(64 * T) fill_affine_kernel(const DeviceBatch A) {
   using G_ = Geo<S>;
   using R_ = Rec<S, 9>;
   constexpr int W = G_::W, R = G_::R, RR = G_::RR, PADB = G_::PADB;
@@ -224,7 +242,8 @@ __global__ void __launch_bounds__(64) fill_affine_kernel(const DeviceBatch A) {
 
   const PairDesc pd = A.pairs[A.order[blockIdx.x]];
   const int n = pd.n, m = pd.m, P = pd.P;
-  const int L = threadIdx.x;
+  const int L = threadIdx.x & 63;
+  const int w = T == 1 ? 0 : __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave in team
   const int il = L / W, aa = L - il * W;
   const bool live = L < R * W;
   const bool ghost = (il == 0);
@@ -232,27 +251,29 @@ __global__ void __launch_bounds__(64) fill_affine_kernel(const DeviceBatch A) {
   const int k1 = A.k1, k2 = A.k2;
   const int gD = gamma + delta, gg = 2 * gamma, ggdd = 2 * gamma + 2 * delta, dd = 2 * delta;
 
-  // ---- LDS carve-up
+  // ---- LDS carve-up: per wave a ghost ring and an exchange array; shared: progress
+  //      words, score tables, sequence codes
   using GF = GhostFeed<S, 9>;
-  v4i* ring = reinterpret_cast<v4i*>(smem);     // ghost-row ring, two halves
-  int32_t* xch = smem + GF::RING_DW;            // [NV][NCOL] exchange array
-  int32_t* s1 = xch + NV * NCOL;                // [k1*k1]
-  int32_t* s2 = s1 + k1 * k1;                   // [k2*k2]
+  v4i* ring = reinterpret_cast<v4i*>(smem + w * GF::RING_DW);   // ghost-row ring, two halves
+  int32_t* xch = smem + T * GF::RING_DW + w * (NV * NCOL);      // [NV][NCOL] exchange array
+  volatile int32_t* prog = smem + T * (GF::RING_DW + NV * NCOL); // [4] steps with stores acknowledged
+  int32_t* s1 = smem + T * (GF::RING_DW + NV * NCOL) + 4;       // [k1*k1]
+  int32_t* s2 = s1 + k1 * k1;                                   // [k2*k2]
   const int npad = (n + 3) & ~3, mpad = (m + 2 * PADB + 3) & ~3;
   uint8_t* sa = reinterpret_cast<uint8_t*>(s2 + k2 * k2);  // seq A codes, [i-1]
   uint8_t* ca = sa + npad;                                  // cls A,       [k-1]
   uint8_t* sb = ca + npad;                                  // seq B codes, [j-1+PADB]
   uint8_t* cb = sb + mpad;                                  // cls B,       [l-1+PADB]
 
-  for (int t = L; t < GF::RING_DW; t += 64) smem[t] = SENT;
-  for (int t = L; t < NV * NCOL; t += 64) xch[t] = SENT;
-  for (int t = L; t < k1 * k1; t += 64) s1[t] = A.s1[t];
-  for (int t = L; t < k2 * k2; t += 64) s2[t] = A.s2[t];
-  for (int t = L; t < n; t += 64) {
+  for (int t = threadIdx.x; t < T * (GF::RING_DW + NV * NCOL); t += 64 * T) smem[t] = SENT;
+  if (threadIdx.x < 4) prog[threadIdx.x] = 0;
+  for (int t = threadIdx.x; t < k1 * k1; t += 64 * T) s1[t] = A.s1[t];
+  for (int t = threadIdx.x; t < k2 * k2; t += 64 * T) s2[t] = A.s2[t];
+  for (int t = threadIdx.x; t < n; t += 64 * T) {
     sa[t] = A.seq_a[pd.seq_a + t];
     ca[t] = A.cls_a[pd.seq_a + t];
   }
-  for (int t = L; t < m + 2 * PADB; t += 64) {
+  for (int t = threadIdx.x; t < m + 2 * PADB; t += 64 * T) {
     const int src = t - PADB;
     const bool ok = src >= 0 && src < m;
     sb[t] = ok ? A.seq_b[pd.seq_b + src] : 0;
@@ -267,13 +288,19 @@ __global__ void __launch_bounds__(64) fill_affine_kernel(const DeviceBatch A) {
   const int GOFF = P - 2 * (R - 1);  // steps between a bottom row and its ghost copy
   int32_t* const lay = A.layers + pd.layer_off;
 
+  const int rec_last = pd.G - 1;     // last record of this pair
+  // local steps of this wave: its strips are w, w+T, ... (NSw of them)
+  const int NSw = (pd.NS - w + T - 1) / T;
+  const int H = NSw > 0 ? (NSw - 1) * P + m + G_::MAXOFF + 1 : 0;
+
   // ---- per-lane sweep state
   int jj = -(2 * il + aa);  // column of this step (< 0: not started)
-  int strip = 0;
+  int strip = 0;            // local strip index q; lattice strip = q*T + w
+  int rec_base = w * P;     // record of local step h for this lane = h + rec_base
   int i = 0, s1row = 0, s2row = 0;
   bool act_row = false;
-  auto set_row = [&](int st) {
-    i = st * RR + il - 1;
+  auto set_row = [&](int q) {
+    i = (q * T + w) * RR + il - 1;
     const int k = i + aa - S;
     act_row = live && i >= 0 && i <= n && k >= 0 && k <= n;
     s1row = (i >= 1 && i <= n) ? sa[i - 1] * k1 : 0;
@@ -301,7 +328,36 @@ __global__ void __launch_bounds__(64) fill_affine_kernel(const DeviceBatch A) {
 #pragma unroll
   for (int d = 0; d < ND; ++d) ghostM[d] = SENT;
   const uint32_t ring_lds = __builtin_amdgcn_readfirstlane(
-      (uint32_t)(uintptr_t)(__attribute__((address_space(3))) int32_t*)smem);
+      (uint32_t)(uintptr_t)(__attribute__((address_space(3))) int32_t*)smem) + w * GF::RING_DW * 4;
+
+  // ---- team protocol (T > 1): partner progress needed before prefetching the ghost
+  //      block whose last local step is h_last
+  int blk_q = 0, blk_rem = 0;  // (next block start) div / mod P
+  bool team_failed = false;
+  auto wait_partner = [&](int h_last) __attribute__((always_inline)) {
+    if (T == 1 || team_failed) return;
+    const int src = w == 0 ? T - 1 : w - 1;
+    const int need = h_last + 2 * (R - 1) + 1 - (w == 0 ? P : 0);
+    // bounded spin: a protocol bug must surface as an error, never as a hung GPU
+    for (int spin = 0; prog[src] < need; ++spin) {
+      if (spin > (1 << 20)) {  // ~0.5 s; then fail fast: no further waits, host reports the error
+        if (L == 0) atomicExch(A.errflag, 1);
+        team_failed = true;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(16);
+    }
+  };
+  auto prefetch_block = [&](int h0, int half) __attribute__((always_inline)) {
+    // h0 = first local step of the block; blk_q/blk_rem describe h0
+    wait_partner(h0 + GF::BLK - 1);
+    GF::template issue<T>(lay, h0, blk_q, blk_rem, P, w, GOFF, rec_last, L, ring_lds + half * GF::SLOTS * 16);
+    blk_rem += GF::BLK;
+    if (blk_rem >= P) { blk_rem -= P; ++blk_q; }
+  };
+  // block 0 must be in the ring before the first step (waves w >= 1 start on a real ghost row)
+  prefetch_block(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
   // One step of the sweep.  INTERIOR steps (every lane's lattice points have all
   // four coordinates >= 1 and lie inside the molecule columns; ~90 % of the
@@ -310,13 +366,14 @@ __global__ void __launch_bounds__(64) fill_affine_kernel(const DeviceBatch A) {
   // out-of-lattice bookkeeping disappears; boundary steps take the general form.
   auto step = [&](auto interior_tag, int g) __attribute__((always_inline)) {
     constexpr bool INTERIOR = decltype(interior_tag)::value;
-    // ---- 0. ghost feed: at a block boundary retire last block's DMAs and start the
-    //         next block's (before this step's stores); then pick this step's ghost
-    //         layers out of the ring
+    // ---- 0. ghost feed: at a block boundary retire last block's DMAs (which also tells
+    //         how far this wave's own stores are acknowledged), start the next block's
+    //         (before this step's stores); then pick this step's ghost layers out of the ring
     const int gt = g & (GF::BLK - 1), ghalf = (g / GF::BLK) & 1;
     if (gt == 0) {
       GF::wait_block();
-      GF::issue(lay, (g / GF::BLK + 1) * GF::BLK, GOFF, L, ring_lds + (ghalf ^ 1) * GF::SLOTS * 16);
+      if (T > 1 && L == 0) prog[w] = g - 8;  // <= 40 vector-memory ops pending = < 6 steps of stores
+      prefetch_block(g + GF::BLK, ghalf ^ 1);
     }
     GF::fetch(ghostM, ring + ghalf * GF::SLOTS, gt, aa);
 
@@ -358,7 +415,7 @@ __global__ void __launch_bounds__(64) fill_affine_kernel(const DeviceBatch A) {
       const int mu2v = mu2[bb];
       const int c_MM = mu1 + mu2v, c_gM = mu2v + gD, c2M = mu2v + dd;
 
-      int T[9];
+      int Tv[9];
 #pragma unroll
       for (int hU = 0; hU < 3; ++hU) {
 #pragma unroll
@@ -400,7 +457,7 @@ __global__ void __launch_bounds__(64) fill_affine_kernel(const DeviceBatch A) {
           if (ok1) { t = c1 + gin; any = true; }
           if (ok2) { t = any ? imax(t, c2 + h2in) : c2 + h2in; any = true; }
           if (ok3) { t = any ? imax(t, c3 + h3in) : c3 + h3in; any = true; }
-          T[3 * hU + hV] = t;
+          Tv[3 * hU + hV] = t;
         }
       }
 
@@ -410,7 +467,7 @@ __global__ void __launch_bounds__(64) fill_affine_kernel(const DeviceBatch A) {
       if (INTERIOR) {
 #pragma unroll
         for (int q = 0; q < 9; ++q) {
-          int tv = ghost ? ghostM[bb * 9 + q] : T[q];
+          int tv = ghost ? ghostM[bb * 9 + q] : Tv[q];
           if (can_be_empty<W>(q / 3, q % 3, bb)) tv = tv < THRESH ? NEG : tv;
           M[q] = tv;
         }
@@ -418,7 +475,7 @@ __global__ void __launch_bounds__(64) fill_affine_kernel(const DeviceBatch A) {
         const int low = act ? NEG : SENT;
 #pragma unroll
         for (int q = 0; q < 9; ++q) {
-          const int tv = ghost ? ghostM[bb * 9 + q] : T[q];
+          const int tv = ghost ? ghostM[bb * 9 + q] : Tv[q];
           const bool bad = (tv < THRESH) | !act;
           M[q] = bad ? low : tv;
         }
@@ -506,9 +563,11 @@ __global__ void __launch_bounds__(64) fill_affine_kernel(const DeviceBatch A) {
     // lattice points that exist; ghost lanes, lane 63 and out-of-lattice rows store
     // don't-care values there so that the wave always writes whole 1 KiB runs (full
     // HBM sectors, no masked partial writes).  Only fully idle steps skip the store.
-    if (BIALIGN_EXP != 1 && (INTERIOR || __builtin_amdgcn_ballot_w64(tile_act && !ghost) != 0)) {
+    const int rec = g + rec_base;  // lanes of two strips (straddling steps) hit two records
+    if (BIALIGN_EXP != 1 && (INTERIOR || __builtin_amdgcn_ballot_w64(tile_act && !ghost) != 0) &&
+        (T == 1 || rec <= rec_last)) {
       int32_t* dst = BIALIGN_EXP == 2 ? A.layers + ((int64_t)(blockIdx.x & 255) << 18) + (int64_t)(g & 31) * RECDW
-                                      : lay + (int64_t)g * RECDW;
+                                      : lay + (int64_t)rec * RECDW;
 #pragma unroll
       for (int c = 0; c < NCH4; ++c) {
         v4i v;
@@ -524,6 +583,7 @@ __global__ void __launch_bounds__(64) fill_affine_kernel(const DeviceBatch A) {
     if (jj == P) {
       jj = 0;
       ++strip;
+      rec_base += (T - 1) * P;
       set_row(strip);
     }
   };
@@ -534,16 +594,20 @@ __global__ void __launch_bounds__(64) fill_affine_kernel(const DeviceBatch A) {
     const bool lane_interior = !live || (jj >= S + 1 && jj <= m && i >= S + 1);
     return __builtin_amdgcn_ballot_w64(lane_interior) == ~0ull;
   };
-  int g = 0;
-  while (g < pd.G) {
-    while (g < pd.G && (BIALIGN_EXP == 3 || (BIALIGN_EXP != 4 && !all_interior()))) {
+  int g = 0;  // local step of this wave
+  while (g < H) {
+    while (g < H && (BIALIGN_EXP == 3 || (BIALIGN_EXP != 4 && !all_interior()))) {
       step(BoolTag<false>{}, g);
       ++g;
     }
-    while (g < pd.G && BIALIGN_EXP != 3 && (BIALIGN_EXP == 4 || all_interior())) {
+    while (g < H && BIALIGN_EXP != 3 && (BIALIGN_EXP == 4 || all_interior())) {
       step(BoolTag<true>{}, g);
       ++g;
     }
+  }
+  if (T > 1) {  // everything this wave wrote is acknowledged: release the partner for good
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (L == 0) prog[w] = 0x7fffffff;
   }
 }
 
@@ -765,7 +829,8 @@ __global__ void __launch_bounds__(64) fill_linear_kernel(const DeviceBatch A) {
     const int gt = g & (GF::BLK - 1), ghalf = (g / GF::BLK) & 1;
     if (gt == 0) {
       GF::wait_block();
-      GF::issue(lay, (g / GF::BLK + 1) * GF::BLK, GOFF, L, ring_lds + (ghalf ^ 1) * GF::SLOTS * 16);
+      GF::template issue<1>(lay, (g / GF::BLK + 1) * GF::BLK, 0, 0, P, 0, GOFF, pd.G - 1, L,
+                            ring_lds + (ghalf ^ 1) * GF::SLOTS * 16);
     }
     GF::fetch(ghostM, ring + ghalf * GF::SLOTS, gt, aa);
     int inLW[W], inLW1[W], inL1[W];

@@ -103,3 +103,26 @@ def test_ragged_batch_vs_oracle():
             assert trace_codes_to_columns(traces[t]) == oracle.trace_to_lists(ref["trace"])
             assert bool(ok[t]) == ref["complete"]
         b.close()
+
+
+@pytest.mark.parametrize("n,m,s,seed", [(300, 300, 1, 21), (130, 420, 1, 22), (420, 330, 0, 23)])
+def test_team_sweep_full_layers(n, m, s, seed, monkeypatch):
+    """Two waves per pair on alternating strips (forced): every layer cell, trace and score."""
+    monkeypatch.setenv("BIALIGN_TEAM", "2")
+    test_full_layers_vs_oracle(n, m, s, seed)
+
+
+def test_team_sweep_batch_matches_single_wave(monkeypatch):
+    """Default policy picks two waves per pair for this batch; results equal the one-wave sweep."""
+    from bialign_amd.batch import make_batch
+    pairs = synth.protein_batch(48, 512)
+    params = dict(synth.PROTEIN_PARAMS)
+    out = {}
+    for team in ("1", "2"):
+        monkeypatch.setenv("BIALIGN_TEAM", team)
+        b = make_batch(pairs, params)
+        b.run()
+        traces, ok = b.traces()
+        out[team] = (b.scores().tolist(), [t.tolist() for t in traces], ok.tolist())
+        b.close()
+    assert out["1"] == out["2"]
