@@ -617,14 +617,23 @@ __device__ __forceinline__ int shift_of(int hU, int hV) {
 }
 
 // ---------------------------------------------------------------------------
-// Affine traceback (pyx:535-586).  One thread per pair; every step issues the
-// up-to-15 candidate loads together, so a column costs one HBM round trip.
+// Affine traceback (pyx:535-586).  One wave per pair: lane c < 15 owns candidate
+// c of the case generator's order (pyx:275-296) -- nine sources of the full
+// offset, then three of the structure-only and three of the sequence-only offset
+// -- so a column costs one HBM round trip and a handful of instructions.  The
+// tie-break of pyx:554-565 ("first candidate minimising [|d0|+|d1|, |d1|]" with
+// the source state added as a one-step look-ahead) is a wave-min over the packed
+// key (|d0|+|d1|, |d1|, c).
 // ---------------------------------------------------------------------------
+__device__ __forceinline__ int wave_min16(int v) {  // min over lanes 0..15, valid in every lane < 16
+#pragma unroll
+  for (int d = 1; d < 16; d <<= 1) v = min(v, __shfl_xor(v, d, 16));
+  return v;
+}
+
 template <int S, bool DO_TRACE>
 __global__ void __launch_bounds__(64) traceback_affine_kernel(const DeviceBatch A, int npairs) {
-  const int slot = blockIdx.x * 64 + threadIdx.x;
-  if (slot >= npairs) return;
-  const int pid = A.order[slot];
+  const int pid = A.order[blockIdx.x];
   const PairDesc pd = A.pairs[pid];
   const int n = pd.n, m = pd.m;
   const int beta = A.beta, gamma = A.gamma, delta = A.delta;
@@ -633,27 +642,23 @@ __global__ void __launch_bounds__(64) traceback_affine_kernel(const DeviceBatch 
   const uint8_t* ca = A.cls_a + pd.seq_a;
   const uint8_t* sb = A.seq_b + pd.seq_b;
   const uint8_t* cb = A.cls_b + pd.seq_b;
+  const int c = threadIdx.x;  // candidate lane
+  constexpr int BIG = 0x7fffffff;
 
   // pyx:573-582: best end layer, first one with the least shift
-  int endv[9];
-#pragma unroll
-  for (int q = 0; q < 9; ++q) endv[q] = lay[cell_dword<S, 9>(pd, n, m, S, S, q)];
-  int best = endv[0];
-#pragma unroll
-  for (int q = 1; q < 9; ++q) best = imax(best, endv[q]);
-  A.scores[pid] = best;
+  const int endv = c < 9 ? lay[cell_dword<S, 9>(pd, n, m, S, S, c)] : -BIG;
+  const int best = __builtin_amdgcn_readfirstlane(-wave_min16(-endv));
+  if (c == 0) A.scores[pid] = best;
   if (!DO_TRACE) return;
-
-  int st = -1, stkey = 0;
-#pragma unroll
-  for (int q = 0; q < 9; ++q) {
-    const int sh = shift_of(q / 3, q % 3);
-    if (endv[q] == best && (st < 0 || sh < stkey)) { st = q; stkey = sh; }
-  }
+  const int skey = (c < 9 && endv == best) ? (shift_of(c / 3, c % 3) << 4 | c) : BIG;
+  int st = __builtin_amdgcn_readfirstlane(wave_min16(skey)) & 15;
 
   uint8_t* out = A.trace + pd.trace_off;
   int i = n, j = m, k = n, l = m, d0 = 0, d1 = 0, len = 0, complete = 0;
   int cur = best;
+  // lane-constant part of the candidate: its group and, for groups 2/3, the free half h
+  const int grp = c < 9 ? 1 : (c < 12 ? 2 : 3);
+  const int hfree = grp == 2 ? 2 - (c - 9) : 2 - (c - 12);  // h = M, X, Y in the generator's order
   while (true) {
     if (i == 0 && j == 0 && k == 0 && l == 0 && st == 8) { complete = 1; break; }
     const int hU = st / 3, hV = st - 3 * hU;
@@ -662,86 +667,48 @@ __global__ void __launch_bounds__(64) traceback_affine_kernel(const DeviceBatch 
     const int mu2 = (k >= 1 && l >= 1) ? A.s2[ca[k - 1] * A.k2 + cb[l - 1]] : 0;
     const int valU = hU == 2 ? mu1 : gamma, valV = hV == 2 ? mu2 : gamma;
 
-    // candidate predecessors in the generator's order (pyx:275-296):
-    // cld = stored layer value of the predecessor, csc = score of the column
-    int cld[15], csc[15], csrc[15];
-    bool cok[15];
-    {  // group 1, offset (U,V)
-      const int pi = i - u0, pj = j - u1, pk = k - v0, pl = l - v1;
-      const bool ok = pi >= 0 && pj >= 0 && pk >= 0 && pl >= 0 && abs(pk - pi) <= S && abs(pl - pj) <= S;
-      const int base = delta * shift_of(hU, hV) + valU + valV;
-#pragma unroll
-      for (int ss = 0; ss < 9; ++ss) {
-        const int ra = ss / 3, rb = ss - 3 * (ss / 3);
-        cok[ss] = ok;
-        csrc[ss] = ss;
-        csc[ss] = base + ((hU != 2 && ra != hU) ? beta : 0) + ((hV != 2 && rb != hV) ? beta : 0);
-        cld[ss] = ok ? lay[cell_dword<S, 9>(pd, pi, pj, pk - pi + S, pl - pj + S, ss)] : 0;
-      }
-    }
-    {  // group 2, offset (0,0,V), sources (U,h) for h = M, X, Y
-      const int pk = k - v0, pl = l - v1;
-      const bool ok = pk >= 0 && pl >= 0 && abs(pk - i) <= S && abs(pl - j) <= S;
-      const int base = delta * (v0 + v1) + valV;
-#pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        const int h = 2 - c, ss = 3 * hU + h;
-        cok[9 + c] = ok;
-        csrc[9 + c] = ss;
-        csc[9 + c] = base + ((hV != 2 && h != hV) ? beta : 0);
-        cld[9 + c] = ok ? lay[cell_dword<S, 9>(pd, i, j, pk - i + S, pl - j + S, ss)] : 0;
-      }
-    }
-    {  // group 3, offset (U,0,0), sources (h,V)
-      const int pi = i - u0, pj = j - u1;
-      const bool ok = pi >= 0 && pj >= 0 && abs(k - pi) <= S && abs(l - pj) <= S;
-      const int base = delta * (u0 + u1) + valU;
-#pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        const int h = 2 - c, ss = 3 * h + hV;
-        cok[12 + c] = ok;
-        csrc[12 + c] = ss;
-        csc[12 + c] = base + ((hU != 2 && h != hU) ? beta : 0);
-        cld[12 + c] = ok ? lay[cell_dword<S, 9>(pd, pi, pj, k - pi + S, l - pj + S, ss)] : 0;
-      }
-    }
-    // pyx:554-565: keep cases reproducing the cell, pick the first one that
-    // minimises [|d0|+|d1|, |d1|] after adding the offset AND the source state
-    int pick = -1, key0 = 0, key1 = 0;
-#pragma unroll
-    for (int c = 0; c < 15; ++c) {
-      if (!cok[c] || cld[c] + csc[c] != cur) continue;
-      const int o0 = c < 12 ? (c < 9 ? u0 : 0) : u0, o1 = c < 12 ? (c < 9 ? u1 : 0) : u1;
-      const int o2 = c < 12 ? v0 : 0, o3 = c < 12 ? v1 : 0;
-      const int ra = csrc[c] / 3, rb = csrc[c] - 3 * ra;
-      const int r0 = ra >= 1, r1 = ra != 1, r2 = rb >= 1, r3 = rb != 1;
-      const int t0 = d0 + (o0 - o2) + (r0 - r2), t1 = d1 + (o1 - o3) + (r1 - r3);
-      const int ka = abs(t0) + abs(t1), kb = abs(t1);
-      if (pick < 0 || ka < key0 || (ka == key0 && kb < key1)) { pick = c; key0 = ka; key1 = kb; }
-    }
-    if (pick < 0) break;  // pyx:570-571 -> "incomplete traceback"
-    const int o0 = pick < 12 ? (pick < 9 ? u0 : 0) : u0, o1 = pick < 12 ? (pick < 9 ? u1 : 0) : u1;
-    const int o2 = pick < 12 ? v0 : 0, o3 = pick < 12 ? v1 : 0;
-    d0 += o0 - o2;  // pyx:566: only the offset moves the running shift
-    d1 += o1 - o3;
-    if (len < pd.trace_cap) out[len] = (uint8_t)(o0 * 8 + o1 * 4 + o2 * 2 + o3);
+    // this lane's candidate: offset, source state, score (pyx:84-131)
+    const int o0 = grp == 2 ? 0 : u0, o1 = grp == 2 ? 0 : u1;
+    const int o2 = grp == 3 ? 0 : v0, o3 = grp == 3 ? 0 : v1;
+    const int ss = grp == 1 ? c : (grp == 2 ? 3 * hU + hfree : 3 * hfree + hV);
+    const int ra = ss / 3, rb = ss - 3 * ra;
+    const int openU = (hU != 2 && ra != hU) ? beta : 0, openV = (hV != 2 && rb != hV) ? beta : 0;
+    const int sc = grp == 1   ? delta * shift_of(hU, hV) + valU + valV + openU + openV
+                   : grp == 2 ? delta * (v0 + v1) + valV + openV
+                              : delta * (u0 + u1) + valU + openU;
+    const int pi = i - o0, pj = j - o1, pk = k - o2, pl = l - o3;
+    const bool ok = c < 15 && pi >= 0 && pj >= 0 && pk >= 0 && pl >= 0 && abs(pk - pi) <= S &&
+                    abs(pl - pj) <= S;  // pyx:133-141
+    const int ld = ok ? lay[cell_dword<S, 9>(pd, pi, pj, pk - pi + S, pl - pj + S, ss)] : 0;
+    // pyx:554-565: cases reproducing the cell; look-ahead adds the offset AND the source state
+    const int r0 = ra >= 1, r1 = ra != 1, r2 = rb >= 1, r3 = rb != 1;
+    const int t0 = d0 + (o0 - o2) + (r0 - r2), t1 = d1 + (o1 - o3) + (r1 - r3);
+    const int key = (ok && ld + sc == cur) ? ((abs(t0) + abs(t1)) << 16 | abs(t1) << 8 | c) : BIG;
+    const int kmin = __builtin_amdgcn_readfirstlane(wave_min16(key));
+    if (kmin == BIG) break;  // pyx:570-571 -> "incomplete traceback"
+    const int pick = kmin & 63;
+    const int code = __builtin_amdgcn_readlane(o0 * 8 + o1 * 4 + o2 * 2 + o3, pick);
+    st = __builtin_amdgcn_readlane(ss, pick);
+    cur = __builtin_amdgcn_readlane(ld, pick);
+    const int q0 = (code >> 3) & 1, q1 = (code >> 2) & 1, q2 = (code >> 1) & 1, q3 = code & 1;
+    d0 += q0 - q2;  // pyx:566: only the offset moves the running shift
+    d1 += q1 - q3;
+    if (c == 0 && len < pd.trace_cap) out[len] = (uint8_t)code;
     ++len;
-    i -= o0; j -= o1; k -= o2; l -= o3;
-    int nst = 0, ncur = 0;
-#pragma unroll
-    for (int c = 0; c < 15; ++c)
-      if (c == pick) { nst = csrc[c]; ncur = cld[c]; }
-    st = nst;
-    cur = ncur;
+    i -= q0; j -= q1; k -= q2; l -= q3;
   }
   if (len > pd.trace_cap) len = pd.trace_cap;
-  for (int x = 0, y = len - 1; x < y; ++x, --y) {  // pyx:586 reversed
+  __builtin_amdgcn_s_waitcnt(0);  // lane 0's byte stores before the wave-wide reversal
+  __syncthreads();
+  for (int x = c; x < len / 2; x += 64) {  // pyx:586 reversed
     const uint8_t t = out[x];
-    out[x] = out[y];
-    out[y] = t;
+    out[x] = out[len - 1 - x];
+    out[len - 1 - x] = t;
   }
-  A.trace_len[pid] = len;
-  A.complete[pid] = complete;
+  if (c == 0) {
+    A.trace_len[pid] = len;
+    A.complete[pid] = complete;
+  }
 }
 
 // ---------------------------------------------------------------------------
