@@ -128,3 +128,33 @@ def test_properties_linear_and_wide_band():
                     dict(synth.PROTEIN_PARAMS, gap_opening_cost=0, gap_cost=-200, shift_cost=-250, max_shift=2))
     _property_check(synth.protein_batch(8, 200, 333), dict(synth.PROTEIN_PARAMS, max_shift=3))
     _property_check(synth.rna_batch(8, 400), dict(synth.RNA_PARAMS, max_shift=0))
+
+
+def test_full_config2_team_vs_single_wave_under_load(monkeypatch):
+    """BASELINE config 2 at full size (1024 pairs, 95 GB of layers, every SIMD busy): the
+    two-waves-per-pair sweep and the one-wave sweep agree on every score and trace, and every
+    trace re-scores to its optimum -- the hand-off between waves is timing dependent, so it is
+    checked under the real load, not only on small cases."""
+    from bialign_amd.batch import encode_pairs
+    from bialign_amd.engine import Batch, default_engine
+    from bialign_amd.verify import rescore_trace
+    params = dict(synth.PROTEIN_PARAMS)
+    pairs = synth.protein_batch(1024, 512)
+    model, mols_a, mols_b = encode_pairs(pairs, params)
+    got = {}
+    for team in ("2", "1"):
+        monkeypatch.setenv("BIALIGN_TEAM", team)
+        b = Batch(default_engine(), mols_a, mols_b, model.s1, model.s2, params["gap_opening_cost"],
+                  params["gap_cost"], params["shift_cost"], params["max_shift"])
+        b.run()
+        traces, ok = b.traces()
+        got[team] = (b.scores().copy(), traces, ok.copy())
+        b.close()
+    np.testing.assert_array_equal(got["1"][0], got["2"][0])
+    assert all(np.array_equal(x, y) for x, y in zip(got["1"][1], got["2"][1]))
+    scores, traces, ok = got["2"]
+    assert ok.all()
+    for p in range(0, 1024, 3):
+        total, consumed, drift = rescore_trace(traces[p], mols_a[p][0], mols_a[p][1], mols_b[p][0], mols_b[p][1],
+                                               model.s1, model.s2, -150, -50, -150, True)
+        assert total == int(scores[p]) and consumed == (512, 512, 512, 512) and drift <= 1
