@@ -110,7 +110,8 @@ struct bialign_batch {
   std::vector<int32_t> order;       // chunk-by-chunk launch order
   std::vector<int> chunk_begin;     // index into order, size nchunks+1
   int64_t cells = 0, trace_bytes = 0, max_chunk_dwords = 0;
-  size_t lds_bytes = 0, lds_bytes_team = 0;  // dynamic LDS per workgroup: one wave / two waves per pair
+  size_t lds_bytes = 0;                   // dynamic LDS of a one-wave workgroup
+  size_t lds_base = 0, lds_per_wave = 0;  // team launches: lds_base + T * lds_per_wave
   DevBuf<PairDesc> d_pairs;
   DevBuf<int32_t> d_order, d_s1, d_s2, d_layers, d_scores, d_tlen, d_complete, d_err;
   DevBuf<uint8_t> d_seq_a, d_cls_a, d_seq_b, d_cls_b, d_trace;
@@ -144,7 +145,7 @@ size_t lds_need(int S, int NL, int team, int k1, int k2, int n, int m) {
   const size_t npad = (n + 3) & ~3, mpad = (m + 2 * PADB + 3) & ~3;
   const int nd = NL * W, np = nd / 4 + (nd % 4 ? 1 : 0), blk = ghost_blk(S);
   const size_t ring_dw = 2 * (((size_t)blk * W * np + 63) / 64 * 64) * 4;  // GhostFeed<S,NL>::RING_DW
-  const size_t shared_dw = (NL == 9 ? 4 : 0) + (size_t)k1 * k1 + (size_t)k2 * k2;
+  const size_t shared_dw = (NL == 9 ? 16 : 0) + (size_t)k1 * k1 + (size_t)k2 * k2;
   return (team * (ring_dw + nv * NCOL) + shared_dw) * 4 + 2 * npad + 2 * mpad;
 }
 
@@ -153,7 +154,7 @@ int launch_fill_affine_t(const bialign_batch* b, const DeviceBatch& v, int first
   DeviceBatch w = v;
   w.order = v.order + first;
   auto kern = fill_affine_kernel<S, BETA_NONPOS, T>;
-  const size_t lds = T == 1 ? b->lds_bytes : b->lds_bytes_team;
+  const size_t lds = b->lds_base + (size_t)T * b->lds_per_wave;
   if (lds > 64 * 1024)
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -162,30 +163,44 @@ int launch_fill_affine_t(const bialign_batch* b, const DeviceBatch& v, int first
   return BIALIGN_OK;
 }
 
-// Waves per pair.  Two waves per pair double the waves per SIMD when a launch has fewer
-// pairs than the chip has wave slots worth filling (256 CUs x 4 SIMDs x 2); they need
-// P >= 256 so that the two waves never wait on each other (see the kernel's header).
+// Waves per pair (team size T).  More waves per pair = more waves per SIMD when a launch
+// has fewer pairs than the chip has wave slots worth filling (256 CUs x 4 SIMDs x 2).
+// Wave w trails wave w-1 by `lag` steps and wave 0 may lead wave T-1 by at most P - lag,
+// so T waves run without mutual waiting only if T*lag (+ margin) fits into P; every wave
+// should also own at least two strips.  Register budget: s<=1 kernels fit 2 waves/SIMD
+// (T<=8), s=2,3 need a whole SIMD's registers per wave (T<=4).
 int team_size(const bialign_batch* b, int first, int count) {
+  if (!b->affine) return 1;
   const int W = 2 * b->S + 1, R = 64 / W;
-  // wave w>=1 trails wave w-1 by 2(R-1)+2*BLK+8 steps and wave 0 leads wave 1 by at most
-  // P minus that: both hold without mutual waiting only if P is at least twice the lag
-  const int p_min = std::max(256, 2 * (2 * (R - 1) + 2 * ghost_blk(b->S) + 16));
-  bool safe = b->affine && b->S <= 1 && b->lds_bytes_team <= 64 * 1024;
-  for (int t = first; safe && t < first + count; ++t)
-    safe = b->pairs[b->order[t]].P >= p_min && b->pairs[b->order[t]].NS >= 4;
-  if (!safe) return 1;
-  if (const char* e = getenv("BIALIGN_TEAM")) return atoi(e) == 2 ? 2 : 1;  // experiments / tests
-  return (count <= 1536 && b->lds_bytes_team <= 40 * 1024) ? 2 : 1;
+  const int lag = 2 * (R - 1) + 2 * ghost_blk(b->S) + 16;
+  int tmax = b->S <= 1 ? 8 : 4;
+  for (int t = first; t < first + count; ++t) {
+    const PairDesc& d = b->pairs[b->order[t]];
+    while (tmax > 1 && (d.P < std::max(256, tmax * lag + 64) || d.NS < 2 * tmax)) tmax >>= 1;
+  }
+  while (tmax > 1 && b->lds_base + (size_t)tmax * b->lds_per_wave > 160 * 1024) tmax >>= 1;
+  if (const char* e = getenv("BIALIGN_TEAM")) {  // experiments / tests; never beyond the safe size
+    const int want = atoi(e);
+    int t = 1;
+    while (t * 2 <= want && t * 2 <= tmax) t *= 2;
+    return t;
+  }
+  int t = 1;  // aim at two waves per SIMD over the whole chip, within 40 KB of LDS per two waves
+  while (t * 2 <= tmax && count * t * 2 <= 2048 + 1024) t *= 2;
+  return t;
 }
 
 template <int S>
 int launch_fill_affine(const bialign_batch* b, const DeviceBatch& v, int first, int count) {
-  const bool np = b->prm.gap_opening_cost <= 0;
-  if (S <= 1 && team_size(b, first, count) == 2)
-    return np ? launch_fill_affine_t<S, true, 2>(b, v, first, count)
-              : launch_fill_affine_t<S, false, 2>(b, v, first, count);
-  return np ? launch_fill_affine_t<S, true, 1>(b, v, first, count)
-            : launch_fill_affine_t<S, false, 1>(b, v, first, count);
+  const int T = team_size(b, first, count);
+  if (b->prm.gap_opening_cost > 0)  // rare: general-beta algebra, one wave per pair
+    return launch_fill_affine_t<S, false, 1>(b, v, first, count);
+  switch (T) {
+    case 8: if constexpr (S <= 1) return launch_fill_affine_t<S, true, 8>(b, v, first, count);
+    case 4: return launch_fill_affine_t<S, true, 4>(b, v, first, count);
+    case 2: return launch_fill_affine_t<S, true, 2>(b, v, first, count);
+    default: return launch_fill_affine_t<S, true, 1>(b, v, first, count);
+  }
 }
 
 template <int S>
@@ -401,8 +416,9 @@ int bialign_batch_create(bialign_engine* eng, const bialign_params* prm, const b
     tot_a = std::max<int64_t>(tot_a, pr->off_a[p] + n);
     tot_b = std::max<int64_t>(tot_b, pr->off_b[p] + m);
     b->lds_bytes = std::max(b->lds_bytes, lds_need(S, b->NL, 1, sc->k1, sc->k2, n, m));
-    b->lds_bytes_team = std::max(b->lds_bytes_team, lds_need(S, b->NL, 2, sc->k1, sc->k2, n, m));
+    b->lds_base = std::max(b->lds_base, lds_need(S, b->NL, 0, sc->k1, sc->k2, n, m));
   }
+  b->lds_per_wave = lds_need(S, b->NL, 1, sc->k1, sc->k2, 1, 1) - lds_need(S, b->NL, 0, sc->k1, sc->k2, 1, 1);
   if (b->lds_bytes > 160 * 1024)
     return fail(BIALIGN_E_UNSUPPORTED, "molecules too long for the LDS staging (%zu bytes needed)", b->lds_bytes);
 

@@ -224,13 +224,14 @@ struct BoolTag {
 // open(h,T) + v[h] <= v[T] + ... lets f_X, f_Y reuse f_M's max3:
 //   f_X(v) = max(v[X], beta + max3(v))     (exact for beta <= 0 only)
 //
-// TEAM = T waves per pair (one workgroup).  Wave w sweeps strips w, w+T, w+2T, ...
-// with the same record layout as a single wave would produce; the only coupling
-// is the ghost feed, which now replays records the partner wave wrote.  Each wave
-// publishes in an LDS word how many of its steps have their stores acknowledged;
-// a wave checks the partner's word once per ghost block before prefetching.  Wave
-// w>=1 therefore trails wave w-1 by >= 2(R-1)+2*BLK+8 steps, wave 0 may lead wave
-// T-1 by at most P-(that): the host picks T=2 only for P >= 256.
+// TEAM = T waves per pair (one workgroup, T <= 16).  Wave w sweeps strips w, w+T,
+// w+2T, ... with the same record layout as a single wave would produce; the only
+// coupling is the ghost feed, which now replays records the previous wave of the
+// ring (w-1, or T-1 for wave 0) wrote.  Each wave publishes in an LDS word how many
+// of its steps have their stores acknowledged; a wave checks its predecessor's word
+// once per ghost block before prefetching.  Wave w>=1 therefore trails wave w-1 by
+// lag >= 2(R-1)+2*BLK+8 steps, and wave 0 may lead wave T-1 by at most P-lag: the
+// host picks T only if T*lag fits into P with room to spare (team_size()).
 template <int S, bool BETA_NONPOS, int T>
 __global__ void __launch_bounds__(64 * T) fill_affine_kernel(const DeviceBatch A) {
   using G_ = Geo<S>;
@@ -256,8 +257,8 @@ __global__ void __launch_bounds__(64 * T) fill_affine_kernel(const DeviceBatch A
   using GF = GhostFeed<S, 9>;
   v4i* ring = reinterpret_cast<v4i*>(smem + w * GF::RING_DW);   // ghost-row ring, two halves
   int32_t* xch = smem + T * GF::RING_DW + w * (NV * NCOL);      // [NV][NCOL] exchange array
-  volatile int32_t* prog = smem + T * (GF::RING_DW + NV * NCOL); // [4] steps with stores acknowledged
-  int32_t* s1 = smem + T * (GF::RING_DW + NV * NCOL) + 4;       // [k1*k1]
+  volatile int32_t* prog = smem + T * (GF::RING_DW + NV * NCOL); // [16] steps with stores acknowledged
+  int32_t* s1 = smem + T * (GF::RING_DW + NV * NCOL) + 16;      // [k1*k1]
   int32_t* s2 = s1 + k1 * k1;                                   // [k2*k2]
   const int npad = (n + 3) & ~3, mpad = (m + 2 * PADB + 3) & ~3;
   uint8_t* sa = reinterpret_cast<uint8_t*>(s2 + k2 * k2);  // seq A codes, [i-1]
@@ -266,7 +267,7 @@ __global__ void __launch_bounds__(64 * T) fill_affine_kernel(const DeviceBatch A
   uint8_t* cb = sb + mpad;                                  // cls B,       [l-1+PADB]
 
   for (int t = threadIdx.x; t < T * (GF::RING_DW + NV * NCOL); t += 64 * T) smem[t] = SENT;
-  if (threadIdx.x < 4) prog[threadIdx.x] = 0;
+  if (threadIdx.x < 16) prog[threadIdx.x] = 0;
   for (int t = threadIdx.x; t < k1 * k1; t += 64 * T) s1[t] = A.s1[t];
   for (int t = threadIdx.x; t < k2 * k2; t += 64 * T) s2[t] = A.s2[t];
   for (int t = threadIdx.x; t < n; t += 64 * T) {

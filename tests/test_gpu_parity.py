@@ -105,10 +105,12 @@ def test_ragged_batch_vs_oracle():
         b.close()
 
 
-@pytest.mark.parametrize("n,m,s,seed", [(300, 300, 1, 21), (130, 420, 1, 22), (420, 330, 0, 23)])
-def test_team_sweep_full_layers(n, m, s, seed, monkeypatch):
-    """Two waves per pair on alternating strips (forced): every layer cell, trace and score."""
-    monkeypatch.setenv("BIALIGN_TEAM", "2")
+@pytest.mark.parametrize("n,m,s,seed,team", [(300, 300, 1, 21, 2), (130, 420, 1, 22, 2), (420, 330, 0, 23, 2),
+                                              (330, 650, 1, 24, 8), (170, 400, 1, 25, 4), (100, 300, 2, 26, 4),
+                                              (80, 300, 3, 27, 4)])
+def test_team_sweep_full_layers(n, m, s, seed, team, monkeypatch):
+    """T waves per pair on interleaved strips (forced): every layer cell, trace and score."""
+    monkeypatch.setenv("BIALIGN_TEAM", str(team))
     test_full_layers_vs_oracle(n, m, s, seed)
 
 
