@@ -235,7 +235,7 @@ int launch_traceback_linear(const bialign_batch* b, const DeviceBatch& v, int fi
                             bool do_trace) {
   DeviceBatch w = v;
   w.order = v.order + first;
-  const int blocks = (count + 63) / 64;
+  const int blocks = count;  // one wave per pair
   if (do_trace)
     hipLaunchKernelGGL((traceback_linear_kernel<S, true>), dim3(blocks), dim3(64), 0, b->eng->stream, w, count);
   else

@@ -878,13 +878,12 @@ __global__ void __launch_bounds__(64) fill_linear_kernel(const DeviceBatch A) {
   }
 }
 
-// Non-affine traceback (pyx:513-531): first case, in generator order, that is
-// guard-valid and reproduces the cell; stops when none does (the origin).
+// Non-affine traceback (pyx:513-531): the first case, in generator order, that is
+// guard-valid and reproduces the cell; stops when none does (the origin).  One wave
+// per pair, lane c < 13 = case c; "first" = wave-min over the matching lane ids.
 template <int S, bool DO_TRACE>
 __global__ void __launch_bounds__(64) traceback_linear_kernel(const DeviceBatch A, int npairs) {
-  const int slot = blockIdx.x * 64 + threadIdx.x;
-  if (slot >= npairs) return;
-  const int pid = A.order[slot];
+  const int pid = A.order[blockIdx.x];
   const PairDesc pd = A.pairs[pid];
   const int n = pd.n, m = pd.m;
   const int gamma = A.gamma, delta = A.delta;
@@ -893,51 +892,54 @@ __global__ void __launch_bounds__(64) traceback_linear_kernel(const DeviceBatch 
   const uint8_t* ca = A.cls_a + pd.seq_a;
   const uint8_t* sb = A.seq_b + pd.seq_b;
   const uint8_t* cb = A.cls_b + pd.seq_b;
+  const int c = threadIdx.x;
+  constexpr int BIG = 0x7fffffff;
   int cur = lay[cell_dword<S, 1>(pd, n, m, S, S, 0)];
-  A.scores[pid] = cur;  // pyx:471
+  if (c == 0) A.scores[pid] = cur;  // pyx:471
   if (!DO_TRACE) return;
 
-  // offsets of the thirteen cases as bit masks o0*8+o1*4+o2*2+o3 (pyx:233-248)
-  constexpr int OFF[13] = {15, 10, 5, 12, 3, 8, 4, 2, 1, 11, 7, 14, 13};
+  // offsets of the thirteen cases as bit masks o0*8+o1*4+o2*2+o3 (pyx:233-248), per lane
+  constexpr int OFF[16] = {15, 10, 5, 12, 3, 8, 4, 2, 1, 11, 7, 14, 13, 0, 0, 0};
+  int code_c = 0;
+#pragma unroll
+  for (int t = 0; t < 13; ++t)
+    if (c == t) code_c = OFF[t];
+  const int o0 = (code_c >> 3) & 1, o1 = (code_c >> 2) & 1, o2 = (code_c >> 1) & 1, o3 = code_c & 1;
+  // score of case c as a*mu1 + b*mu2 + const (pyx:233-248)
+  const int use1 = (c == 0 || c == 3 || c == 11 || c == 12), use2 = (c == 0 || c == 4 || c == 9 || c == 10);
+  const int gD = gamma + delta;
+  const int kconst = c == 0 ? 0 : (c <= 2 ? 2 * gamma : (c <= 4 ? delta : gD));
+
   uint8_t* out = A.trace + pd.trace_off;
   int i = n, j = m, k = n, l = m, len = 0;
   while (true) {
     const int mu1 = (i >= 1 && j >= 1) ? A.s1[sa[i - 1] * A.k1 + sb[j - 1]] : 0;
     const int mu2 = (k >= 1 && l >= 1) ? A.s2[ca[k - 1] * A.k2 + cb[l - 1]] : 0;
-    const int gD = gamma + delta;
-    const int sc[13] = {mu1 + mu2, 2 * gamma, 2 * gamma, mu1 + delta, mu2 + delta, gD, gD, gD, gD,
-                        gD + mu2, gD + mu2, gD + mu1, gD + mu1};
-    int ld[13];
-    bool ok[13];
-#pragma unroll
-    for (int c = 0; c < 13; ++c) {
-      const int o0 = (OFF[c] >> 3) & 1, o1 = (OFF[c] >> 2) & 1, o2 = (OFF[c] >> 1) & 1, o3 = OFF[c] & 1;
-      const int pi = i - o0, pj = j - o1, pk = k - o2, pl = l - o3;
-      ok[c] = pi >= 0 && pj >= 0 && pk >= 0 && pl >= 0 && abs(pk - pi) <= S && abs(pl - pj) <= S;
-      ld[c] = ok[c] ? lay[cell_dword<S, 1>(pd, pi, pj, pk - pi + S, pl - pj + S, 0)] : 0;
-    }
-    int pick = -1, nxt = 0;
-#pragma unroll
-    for (int c = 12; c >= 0; --c)
-      if (ok[c] && ld[c] + sc[c] == cur) { pick = c; nxt = ld[c]; }
-    if (pick < 0) break;
-    int code = 0;
-#pragma unroll
-    for (int c = 0; c < 13; ++c)
-      if (c == pick) code = OFF[c];
-    if (len < pd.trace_cap) out[len] = (uint8_t)code;
+    const int sc = kconst + (use1 ? mu1 : 0) + (use2 ? mu2 : 0);
+    const int pi = i - o0, pj = j - o1, pk = k - o2, pl = l - o3;
+    const bool ok = c < 13 && pi >= 0 && pj >= 0 && pk >= 0 && pl >= 0 && abs(pk - pi) <= S && abs(pl - pj) <= S;
+    const int ld = ok ? lay[cell_dword<S, 1>(pd, pi, pj, pk - pi + S, pl - pj + S, 0)] : 0;
+    const int key = (ok && ld + sc == cur) ? c : BIG;
+    const int pick = __builtin_amdgcn_readfirstlane(wave_min16(key));
+    if (pick == BIG) break;
+    const int code = __builtin_amdgcn_readlane(code_c, pick);
+    cur = __builtin_amdgcn_readlane(ld, pick);
+    if (c == 0 && len < pd.trace_cap) out[len] = (uint8_t)code;
     ++len;
     i -= (code >> 3) & 1; j -= (code >> 2) & 1; k -= (code >> 1) & 1; l -= code & 1;
-    cur = nxt;
   }
   if (len > pd.trace_cap) len = pd.trace_cap;
-  for (int x = 0, y = len - 1; x < y; ++x, --y) {
+  __builtin_amdgcn_s_waitcnt(0);
+  __syncthreads();
+  for (int x = c; x < len / 2; x += 64) {
     const uint8_t t = out[x];
-    out[x] = out[y];
-    out[y] = t;
+    out[x] = out[len - 1 - x];
+    out[len - 1 - x] = t;
   }
-  A.trace_len[pid] = len;
-  A.complete[pid] = 1;
+  if (c == 0) {
+    A.trace_len[pid] = len;
+    A.complete[pid] = 1;
+  }
 }
 
 // ---------------------------------------------------------------------------
