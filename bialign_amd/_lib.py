@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("BIALIGN_LIB_OVERRIDE") or os.path.join(HERE, "libbial
 ABI_VERSION = 2
 RUN_FILL_ONLY = 1
 REC_AUTO, REC_AFFINE, REC_LINEAR = 0, 1, 2
-MAX_SHIFT = 3
+MAX_SHIFT = 5
 
 E_INVALID, E_UNSUPPORTED, E_DEVICE, E_NOMEM, E_RANGE = -1, -2, -3, -4, -5
 

@@ -173,7 +173,7 @@ int team_size(const bialign_batch* b, int first, int count) {
   if (!b->affine) return 1;
   const int W = 2 * b->S + 1, R = 64 / W;
   const int lag = 2 * (R - 1) + 2 * ghost_blk(b->S) + 16;
-  int tmax = b->S <= 1 ? 8 : 4;
+  int tmax = b->S <= 1 ? 8 : (b->S <= 3 ? 4 : 1);
   for (int t = first; t < first + count; ++t) {
     const PairDesc& d = b->pairs[b->order[t]];
     while (tmax > 1 && (d.P < std::max(256, tmax * lag + 64) || d.NS < 2 * tmax)) tmax >>= 1;
@@ -195,12 +195,14 @@ int launch_fill_affine(const bialign_batch* b, const DeviceBatch& v, int first, 
   const int T = team_size(b, first, count);
   if (b->prm.gap_opening_cost > 0)  // rare: general-beta algebra, one wave per pair
     return launch_fill_affine_t<S, false, 1>(b, v, first, count);
-  switch (T) {
-    case 8: if constexpr (S <= 1) return launch_fill_affine_t<S, true, 8>(b, v, first, count);
-    case 4: return launch_fill_affine_t<S, true, 4>(b, v, first, count);
-    case 2: return launch_fill_affine_t<S, true, 2>(b, v, first, count);
-    default: return launch_fill_affine_t<S, true, 1>(b, v, first, count);
+  if constexpr (S <= 1) {
+    if (T == 8) return launch_fill_affine_t<S, true, 8>(b, v, first, count);
   }
+  if constexpr (S <= 3) {  // s >= 4 needs nearly all 512 registers of a SIMD lane: one wave per pair
+    if (T >= 4) return launch_fill_affine_t<S, true, 4>(b, v, first, count);
+    if (T >= 2) return launch_fill_affine_t<S, true, 2>(b, v, first, count);
+  }
+  return launch_fill_affine_t<S, true, 1>(b, v, first, count);
 }
 
 template <int S>
@@ -251,6 +253,8 @@ int launch_fill(const bialign_batch* b, const DeviceBatch& v, int first, int cou
       case 1: return launch_fill_affine<1>(b, v, first, count);
       case 2: return launch_fill_affine<2>(b, v, first, count);
       case 3: return launch_fill_affine<3>(b, v, first, count);
+      case 4: return launch_fill_affine<4>(b, v, first, count);
+      case 5: return launch_fill_affine<5>(b, v, first, count);
     }
   } else {
     switch (b->S) {
@@ -258,6 +262,8 @@ int launch_fill(const bialign_batch* b, const DeviceBatch& v, int first, int cou
       case 1: return launch_fill_linear<1>(b, v, first, count);
       case 2: return launch_fill_linear<2>(b, v, first, count);
       case 3: return launch_fill_linear<3>(b, v, first, count);
+      case 4: return launch_fill_linear<4>(b, v, first, count);
+      case 5: return launch_fill_linear<5>(b, v, first, count);
     }
   }
   return fail(BIALIGN_E_UNSUPPORTED, "no fill kernel for affine=%d max_shift=%d", b->affine, b->S);
@@ -270,6 +276,8 @@ int launch_traceback(const bialign_batch* b, const DeviceBatch& v, int first, in
       case 1: return launch_traceback_affine<1>(b, v, first, count, do_trace);
       case 2: return launch_traceback_affine<2>(b, v, first, count, do_trace);
       case 3: return launch_traceback_affine<3>(b, v, first, count, do_trace);
+      case 4: return launch_traceback_affine<4>(b, v, first, count, do_trace);
+      case 5: return launch_traceback_affine<5>(b, v, first, count, do_trace);
     }
   } else {
     switch (b->S) {
@@ -277,6 +285,8 @@ int launch_traceback(const bialign_batch* b, const DeviceBatch& v, int first, in
       case 1: return launch_traceback_linear<1>(b, v, first, count, do_trace);
       case 2: return launch_traceback_linear<2>(b, v, first, count, do_trace);
       case 3: return launch_traceback_linear<3>(b, v, first, count, do_trace);
+      case 4: return launch_traceback_linear<4>(b, v, first, count, do_trace);
+      case 5: return launch_traceback_linear<5>(b, v, first, count, do_trace);
     }
   }
   return fail(BIALIGN_E_UNSUPPORTED, "no traceback kernel for affine=%d max_shift=%d", b->affine, b->S);
@@ -296,6 +306,8 @@ int launch_dump_any(const bialign_batch* b, const DeviceBatch& v, int pid, int32
       case 1: return launch_dump<1, 9>(b, v, pid, d_out);
       case 2: return launch_dump<2, 9>(b, v, pid, d_out);
       case 3: return launch_dump<3, 9>(b, v, pid, d_out);
+      case 4: return launch_dump<4, 9>(b, v, pid, d_out);
+      case 5: return launch_dump<5, 9>(b, v, pid, d_out);
     }
   } else {
     switch (b->S) {
@@ -303,6 +315,8 @@ int launch_dump_any(const bialign_batch* b, const DeviceBatch& v, int pid, int32
       case 1: return launch_dump<1, 1>(b, v, pid, d_out);
       case 2: return launch_dump<2, 1>(b, v, pid, d_out);
       case 3: return launch_dump<3, 1>(b, v, pid, d_out);
+      case 4: return launch_dump<4, 1>(b, v, pid, d_out);
+      case 5: return launch_dump<5, 1>(b, v, pid, d_out);
     }
   }
   return fail(BIALIGN_E_UNSUPPORTED, "no dump kernel for affine=%d max_shift=%d", b->affine, b->S);
@@ -431,12 +445,20 @@ int bialign_batch_create(bialign_engine* eng, const bialign_params* prm, const b
   b->order.resize(pr->npairs);
   std::iota(b->order.begin(), b->order.end(), 0);
   b->chunk_begin.push_back(0);
-  int64_t used = 0;
+  // as few chunks as the budget allows, of about equal size (an undersized last chunk
+  // would leave SIMDs idle): fill each chunk up to total / nchunks, never beyond the budget
+  int64_t total_dw = 0;
   for (int p = 0; p < pr->npairs; ++p) {
     if (pair_dwords[p] > budget_dw)
       return fail(BIALIGN_E_NOMEM, "pair %d needs %lld bytes of layers, budget is %lld", p,
                   (long long)pair_dwords[p] * 4, (long long)budget);
-    if (used + pair_dwords[p] > budget_dw) {
+    total_dw += pair_dwords[p];
+  }
+  const int64_t want_chunks = (total_dw + budget_dw - 1) / budget_dw;
+  const int64_t target_dw = std::min(budget_dw, (total_dw + want_chunks - 1) / want_chunks);
+  int64_t used = 0;
+  for (int p = 0; p < pr->npairs; ++p) {
+    if (used > 0 && (used + pair_dwords[p] > budget_dw || used >= target_dw)) {
       b->chunk_begin.push_back(p);
       used = 0;
     }

@@ -38,7 +38,7 @@ extern "C" {
 #define BIALIGN_E_NOMEM (-4)       /* a single pair does not fit the HBM budget */
 #define BIALIGN_E_RANGE (-5)       /* scores could leave the int32 safety window */
 
-#define BIALIGN_MAX_SHIFT 3 /* kernels are instantiated for max_shift 0..3 */
+#define BIALIGN_MAX_SHIFT 5 /* kernels are instantiated for max_shift 0..5 */
 #define BIALIGN_NEG_INF (-(1 << 30)) /* the reference's -infinity, pyx:303,484 */
 
 /* bialign_params.recurrence */

@@ -18,7 +18,7 @@ CLI = load_golden("cli_outputs.json")
 
 
 def supported(rec):
-    return rec["params"]["max_shift"] <= 3
+    return rec["params"]["max_shift"] <= 5
 
 
 @pytest.mark.parametrize("rec", [r for r in KNOWN + SMALL if supported(r)], ids=lambda r: r["name"])

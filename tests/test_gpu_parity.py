@@ -64,7 +64,7 @@ def test_medium_traces(rec):
 
 
 @pytest.mark.parametrize("n,m,s,seed", [(130, 75, 1, 5), (75, 130, 2, 6), (200, 200, 0, 7),
-                                         (61, 64, 3, 8), (257, 129, 1, 9)])
+                                         (61, 64, 3, 8), (257, 129, 1, 9), (40, 50, 4, 10), (33, 45, 5, 11)])
 def test_full_layers_vs_oracle(n, m, s, seed):
     """Several strips / ragged shapes: every layer cell against the oracle."""
     from oracle import oracle
