@@ -406,6 +406,20 @@ __global__ void __launch_bounds__(64 * T) fill_affine_kernel(const DeviceBatch A
     const bool is_origin = INTERIOR ? false : (tile_act && i == 0 && jj == 0 && aa == S);
     const int c3M = mu1 + dd, c_Mg = mu1 + gD;
 
+    // Layer stores (pyx:504: M[state][idx] = ...).  Every lane owns a 16-byte slot in each
+    // chunk of its record, read back only for lattice points that exist; ghost lanes, the
+    // idle lane and out-of-lattice rows store don't-care values there so that the wave
+    // always writes whole 1 KiB runs (full 128-byte lines; masked or half-written lines
+    // cost an HBM read-modify-write).  Only fully idle steps skip the store.  Each chunk is
+    // issued as soon as its four values exist, spreading the stores over the step.
+    const int rec = g + rec_base;  // lanes of two strips (straddling steps) hit two records
+    const bool do_store = BIALIGN_EXP != 1 &&
+                          (INTERIOR || __builtin_amdgcn_ballot_w64(tile_act && !ghost) != 0) &&
+                          (T == 1 || rec <= rec_last);
+    int32_t* const dst = BIALIGN_EXP == 2
+                             ? A.layers + ((int64_t)(blockIdx.x & 255) << 18) + (int64_t)(g & 31) * RECDW
+                             : lay + (int64_t)rec * RECDW;
+
     // ---- 3. the W lattice points of this (i, j, a)
     int outv[ND];
     int h2y[3] = {SENT, SENT, SENT};  // H2[U][Y] of point bb-1 (same step, same lane)
@@ -484,6 +498,20 @@ __global__ void __launch_bounds__(64 * T) fill_affine_kernel(const DeviceBatch A
       }
 #pragma unroll
       for (int q = 0; q < 9; ++q) outv[bb * 9 + q] = M[q];
+      if (do_store) {
+#pragma unroll
+        for (int c = 0; c < NCH4; ++c) {
+          if (4 * c + 3 >= bb * 9 && 4 * c + 3 < (bb + 1) * 9) {  // chunk c completes with this point
+            v4i v;
+            v.x = outv[4 * c]; v.y = outv[4 * c + 1]; v.z = outv[4 * c + 2]; v.w = outv[4 * c + 3];
+            *reinterpret_cast<v4i*>(dst + c * 256 + L * 4) = v;
+          }
+        }
+        if (bb == W - 1) {
+#pragma unroll
+          for (int t = 0; t < TAIL; ++t) dst[NCH4 * 256 + L * TAIL + t] = outv[4 * NCH4 + t];
+        }
+      }
 
       // derived values for the successors
       int H2[3][3], H3[3][3], Gd[3][3];
@@ -557,26 +585,6 @@ __global__ void __launch_bounds__(64 * T) fill_affine_kernel(const DeviceBatch A
       for (int v = 0; v < 3; ++v) dB[1 + v][bb] = inB[bb][2 + v];
       dC[0][bb] = inC[bb][0];
       dC[1][bb] = inC[bb][1];
-    }
-
-    // ---- 5. coalesced layer stores (pyx:504: M[state][idx] = ...)
-    // Every lane owns a 16-byte slot in each chunk of the record, read back only for
-    // lattice points that exist; ghost lanes, lane 63 and out-of-lattice rows store
-    // don't-care values there so that the wave always writes whole 1 KiB runs (full
-    // HBM sectors, no masked partial writes).  Only fully idle steps skip the store.
-    const int rec = g + rec_base;  // lanes of two strips (straddling steps) hit two records
-    if (BIALIGN_EXP != 1 && (INTERIOR || __builtin_amdgcn_ballot_w64(tile_act && !ghost) != 0) &&
-        (T == 1 || rec <= rec_last)) {
-      int32_t* dst = BIALIGN_EXP == 2 ? A.layers + ((int64_t)(blockIdx.x & 255) << 18) + (int64_t)(g & 31) * RECDW
-                                      : lay + (int64_t)rec * RECDW;
-#pragma unroll
-      for (int c = 0; c < NCH4; ++c) {
-        v4i v;
-        v.x = outv[4 * c]; v.y = outv[4 * c + 1]; v.z = outv[4 * c + 2]; v.w = outv[4 * c + 3];
-        *reinterpret_cast<v4i*>(dst + c * 256 + L * 4) = v;
-      }
-#pragma unroll
-      for (int t = 0; t < TAIL; ++t) dst[NCH4 * 256 + L * TAIL + t] = outv[4 * NCH4 + t];
     }
 
     // ---- 6. advance
