@@ -5,9 +5,28 @@ trace the GPU returns -- outside the accelerated path but
 needed so that ``decode_trace`` output is byte-identical to the reference
 (bialignment.pyx:835-990; checked against tests/golden/*.json).
 """
+import ctypes
+import os
 from math import sqrt
 
 import numpy as np
+
+_HOST_LIB = None
+
+
+def _host_lib():
+    """libbialign_host.so (bialign_amd/csrc/bialign_host.c, built by bialign_amd.build)."""
+    global _HOST_LIB
+    if _HOST_LIB is None:
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libbialign_host.so")
+        if not os.path.exists(path):
+            raise ImportError(f"{path} not found: run python -m bialign_amd.build")
+        lib = ctypes.CDLL(path)
+        lib.bialign_host_mea.restype = ctypes.c_int
+        lib.bialign_host_mea.argtypes = [ctypes.POINTER(ctypes.c_double), ctypes.c_int, ctypes.c_double,
+                                         ctypes.POINTER(ctypes.c_uint8), ctypes.POINTER(ctypes.c_double)]
+        _HOST_LIB = lib
+    return _HOST_LIB
 
 
 def consensus_sequence(alistrA, alistrB):
@@ -66,7 +85,27 @@ def consensus_sbpp(alistrA, sbppA, alistrB, sbppB):
 
 def mea(sbpp, gamma=3, *, brackets="()"):
     """Maximum expected accuracy structure of a symmetric pair-probability matrix
-    whose diagonal holds the unpaired probabilities (pyx:836-886).
+    whose diagonal holds the unpaired probabilities (pyx:836-886); returns
+    (structure string, accuracy).  Runs the recursion of ``mea_python`` in native
+    code (same doubles, same order, same tie-breaks): at ~2000 alignment columns
+    the Python loop costs tens of seconds per call, far more than the GPU DP."""
+    mat = np.ascontiguousarray(sbpp, dtype=np.float64)
+    n = len(mat) - 1
+    if mat.ndim != 2 or mat.shape[0] != mat.shape[1] or n < 1:
+        return mea_python(sbpp, gamma, brackets=brackets)
+    marks = np.zeros(n, dtype=np.uint8)
+    score = ctypes.c_double()
+    rc = _host_lib().bialign_host_mea(mat.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), n, float(gamma),
+                                      marks.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)), ctypes.byref(score))
+    if rc:
+        raise MemoryError("bialign_host_mea: allocation failed")
+    table = np.array([ord("."), ord(brackets[0]), ord(brackets[1])], dtype=np.uint8)
+    return (table[marks].tobytes().decode("ascii"), np.float64(score.value))
+
+
+def mea_python(sbpp, gamma=3, *, brackets="()"):
+    """Reference-order MEA recursion in Python (pyx:836-886); kept as the readable
+    statement of what bialign_host_mea computes and as its test partner.
 
     Sparse Nussinov-style recursion: F[i][j] = best accuracy of i..j; per right
     end j a candidate list of (k, C) = "j pairs with / is closed from k".  Ties

@@ -158,3 +158,25 @@ def test_full_config2_team_vs_single_wave_under_load(monkeypatch):
         total, consumed, drift = rescore_trace(traces[p], mols_a[p][0], mols_a[p][1], mols_b[p][0], mols_b[p][1],
                                                model.s1, model.s2, -150, -50, -150, True)
         assert total == int(scores[p]) and consumed == (512, 512, 512, 512) and drift <= 1
+
+
+def test_batch_cli_equals_single_pair_cli(tmp_path, capsys):
+    """The batch front end prints, per pair, what the single-pair CLI prints."""
+    from bialign_amd import batch_cli, cli
+    rows = []
+    for t in range(4):
+        sa, sb, ta, tb = synth.protein_pair(300 + t, 20 + 3 * t, 25 - t)
+        rows.append(("a%d" % t, sa, ta, "b%d" % t, sb, tb))
+    f = tmp_path / "pairs.tsv"
+    f.write_text("".join("\t".join(r) + "\n" for r in rows))
+    opts = ["--type", "Protein", "--simmatrix", "BLOSUM62", "--gap_opening_cost", "-150", "--gap_cost", "-50",
+            "--shift_cost", "-150", "--structure_weight", "800", "--max_shift", "1", "--outmode", "sorted", "-v"]
+    batch_cli.main([str(f)] + opts)
+    blocks = capsys.readouterr().out.split(">pair ")[1:]
+    assert len(blocks) == 4
+    for t, (na, sa, ta, nb, sb, tb) in enumerate(rows):
+        cli.main([sa, sb, "--strA", ta, "--strB", tb, "--nameA", na, "--nameB", nb] + opts)
+        single = capsys.readouterr().out
+        head, body = blocks[t].split("\n", 1)
+        assert head == f"{t}\t{na}\t{nb}"
+        assert body == single

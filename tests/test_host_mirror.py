@@ -138,3 +138,29 @@ def test_shard_partition():
         got = [list(shard(n, r, w)) for r in range(w)]
         assert sum(got, []) == list(range(n))
         assert max(map(len, got)) - min(map(len, got)) <= 1
+
+
+def test_native_mea_equals_python_recursion():
+    """bialign_host_mea (C) against the readable recursion, on matrices full of exact ties."""
+    from bialign_amd import presentation as pr
+    rng = np.random.default_rng(5)
+    for n in (1, 2, 4, 9, 40, 90):
+        for _ in range(12):
+            m = np.zeros((n + 1, n + 1))
+            u = np.triu(rng.integers(0, 4, size=(n, n)) / 4.0 * (rng.random((n, n)) < 0.3), 1)
+            m[1:, 1:] = u + u.T
+            np.fill_diagonal(m, rng.integers(0, 3, size=n + 1) / 2.0)
+            fast, slow = pr.mea(m, brackets="[]"), pr.mea_python(m, brackets="[]")
+            assert fast[0] == slow[0] and fast[1] == slow[1]
+
+
+def test_batch_cli_input(tmp_path):
+    from bialign_amd import batch_cli
+    f = tmp_path / "p.tsv"
+    f.write_text("# comment\nA1\tACD\tHHC\tB1\tAD\tHC\n\nA2\tW\tE\tB2\tWK\tEC\n")
+    assert batch_cli.read_pairs(str(f)) == [("A1", "ACD", "HHC", "B1", "AD", "HC"), ("A2", "W", "E", "B2", "WK", "EC")]
+    (tmp_path / "bad.tsv").write_text("A\tB\n")
+    with pytest.raises(ValueError):
+        batch_cli.read_pairs(str(tmp_path / "bad.tsv"))
+    ns = batch_cli.build_parser().parse_args([str(f), "--type", "Protein", "--max_shift", "1", "--outmode", "raw"])
+    assert ns.type == "Protein" and ns.max_shift == 1 and ns.gap_cost == -200 and not hasattr(ns, "seqA")
