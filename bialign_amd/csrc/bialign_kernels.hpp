@@ -390,7 +390,8 @@ __global__ void __launch_bounds__(64 * T) fill_affine_kernel(const DeviceBatch A
       // and the sentinel where a-1 leaves the band
 #pragma unroll
       for (int x = 0; x < 8; ++x) {
-        const int nb = __builtin_amdgcn_update_dpp(SENT, pubC[bb][x], 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+        // (lane 0 reads out of range -> 0 with bound_ctrl; it is an a_first lane anyway)
+        const int nb = __builtin_amdgcn_mov_dpp(pubC[bb][x], 0x138 /* wave_shr:1 */, 0xf, 0xf, true);
         inC[bb][x] = a_first ? SENT : nb;
       }
     }
