@@ -180,3 +180,42 @@ def test_batch_cli_equals_single_pair_cli(tmp_path, capsys):
         head, body = blocks[t].split("\n", 1)
         assert head == f"{t}\t{na}\t{nb}"
         assert body == single
+
+
+def test_c_abi_error_paths():
+    """Bad arguments come back as negative codes with a message; nothing falls back to a CPU path."""
+    import ctypes
+    from bialign_amd import _lib
+    from bialign_amd.batch import make_batch
+    from bialign_amd.engine import Engine
+    pairs = [synth.protein_pair(1, 12, 9)]
+    with pytest.raises(_lib.BialignError) as e:
+        make_batch(pairs, dict(synth.PROTEIN_PARAMS, max_shift=6))
+    assert e.value.code == _lib.E_UNSUPPORTED and "max_shift" in e.value.message
+    with pytest.raises(_lib.BialignError) as e:
+        make_batch(pairs, dict(synth.PROTEIN_PARAMS, structure_weight=1 << 27))
+    assert e.value.code == _lib.E_RANGE
+    with pytest.raises(_lib.BialignError) as e:
+        make_batch([synth.protein_pair(2, 400, 400)], dict(synth.PROTEIN_PARAMS), hbm_budget_bytes=1 << 20)
+    assert e.value.code == _lib.E_NOMEM
+    with pytest.raises(_lib.BialignError) as e:
+        Engine(10 ** 6)
+    assert e.value.code == _lib.E_INVALID
+    b = make_batch(pairs, dict(synth.PROTEIN_PARAMS))
+    out = np.empty(1, dtype=np.int32)
+    rc = _lib.lib.bialign_batch_get_scores(b._h, out.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)))
+    assert rc == _lib.E_INVALID and b"bialign_batch_run" in _lib.lib.bialign_last_error()   # not run yet
+    b.run(fill_only=True)
+    assert int(b.scores()[0]) != 0
+    with pytest.raises(_lib.BialignError):
+        b.traces()                                  # fill-only run has no trace
+    b.close()
+
+
+def test_unknown_residue_and_predicted_structure():
+    from bialign_amd import bialignment as ba
+    b = ba.BiAligner("AJA", "AAA", "HHH", "HHH", **dict(synth.PROTEIN_PARAMS, nameA="A", nameB="B"))
+    with pytest.raises(KeyError):
+        b.optimize()        # reference: KeyError from the similarity matrix look-up (pyx:407)
+    with pytest.raises(ImportError):
+        ba.BiAligner("ACGU", "ACGU", None, None, **dict(synth.RNA_PARAMS, nameA="A", nameB="B"))  # needs ViennaRNA
