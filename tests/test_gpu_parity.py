@@ -128,3 +128,36 @@ def test_team_sweep_batch_matches_single_wave(monkeypatch):
         out[team] = (b.scores().tolist(), [t.tolist() for t in traces], ok.tolist())
         b.close()
     assert out["1"] == out["2"]
+
+
+def test_fuzz_against_oracle():
+    """160 random small problems -- random lengths, max_shift 0..5, both recurrences, random
+    (also positive / zero) costs, random match/mismatch or BLOSUM62, RNA and protein -- every layer
+    cell, score, trace and completeness flag against the CPU oracle."""
+    import random
+    from oracle import oracle
+    rng = random.Random(20261004)
+    checked = 0
+    for case in range(160):
+        s = rng.choice([0, 1, 1, 2, 2, 3, 4, 5])
+        n, m = rng.randint(1, 34), rng.randint(1, 34)
+        rna = rng.random() < 0.4
+        affine = rng.random() < 0.7
+        params = dict(type="RNA" if rna else "Protein", max_shift=s,
+                      gap_opening_cost=(rng.choice([-300, -150, -1, 50]) if affine else 0),
+                      gap_cost=rng.choice([-200, -50, 0, 30]), shift_cost=rng.choice([-250, -150, -10, 0, 40]),
+                      structure_weight=rng.choice([0, 100, 400, 800]),
+                      simmatrix=None if rna or rng.random() < 0.3 else "BLOSUM62",
+                      sequence_match_similarity=rng.choice([100, 300, 0]),
+                      sequence_mismatch_similarity=rng.choice([0, -100, 100]))
+        sa, sb, ta, tb = (synth.rna_pair if rna else synth.protein_pair)(5000 + case, n, m)
+        rec = dict(seqA=sa, seqB=sb, strA=ta, strB=tb, params=params)
+        ref = oracle.solve(sa, sb, ta, tb, params)
+        got = gpu_solve(rec, layers=True)
+        assert got["score"] == ref["score"], (case, params)
+        assert got["trace"] == oracle.trace_to_lists(ref["trace"]), (case, params)
+        assert got["complete"] == ref["complete"], (case, params)
+        for g, e in zip(oracle.band_values(got["layers"], n, m, s), oracle.band_values(ref["layers"], n, m, s)):
+            np.testing.assert_array_equal(g, e, err_msg=str((case, params)))
+        checked += 1
+    assert checked == 160
