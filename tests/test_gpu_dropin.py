@@ -219,3 +219,9 @@ def test_unknown_residue_and_predicted_structure():
         b.optimize()        # reference: KeyError from the similarity matrix look-up (pyx:407)
     with pytest.raises(ImportError):
         ba.BiAligner("ACGU", "ACGU", None, None, **dict(synth.RNA_PARAMS, nameA="A", nameB="B"))  # needs ViennaRNA
+
+
+def test_properties_long_single_pair():
+    """One long pair (5000 x 4000, 6.9 GB of layers, team of 8 waves): trace re-scores to the optimum."""
+    _property_check([synth.protein_pair(77, 5000, 4000)], dict(synth.PROTEIN_PARAMS))
+    _property_check([synth.rna_pair(78, 3000, 3500)], dict(synth.RNA_PARAMS, max_shift=2))
