@@ -225,3 +225,40 @@ def test_properties_long_single_pair():
     """One long pair (5000 x 4000, 6.9 GB of layers, team of 8 waves): trace re-scores to the optimum."""
     _property_check([synth.protein_pair(77, 5000, 4000)], dict(synth.PROTEIN_PARAMS))
     _property_check([synth.rna_pair(78, 3000, 3500)], dict(synth.RNA_PARAMS, max_shift=2))
+
+
+def _full_config_check(pairs, params, sample_every, expect_chunks_over):
+    from bialign_amd.batch import encode_pairs
+    from bialign_amd.engine import Batch, default_engine
+    from bialign_amd.verify import rescore_trace
+    model, mols_a, mols_b = encode_pairs(pairs, params)
+    b = Batch(default_engine(), mols_a, mols_b, model.s1, model.s2, params["gap_opening_cost"],
+              params["gap_cost"], params["shift_cost"], params["max_shift"])
+    assert b.info["nchunks"] > expect_chunks_over          # does not fit HBM at once: chunked
+    b.run()
+    scores = b.scores()
+    traces, ok = b.traces()
+    info = b.info
+    b.close()
+    assert ok.all()
+    for p in range(0, len(pairs), sample_every):
+        total, consumed, drift = rescore_trace(traces[p], mols_a[p][0], mols_a[p][1], mols_b[p][0], mols_b[p][1],
+                                               model.s1, model.s2, params["gap_opening_cost"], params["gap_cost"],
+                                               params["shift_cost"], True)
+        n, m = len(pairs[p][0]), len(pairs[p][1])
+        assert total == int(scores[p]) and consumed == (n, m, n, m) and drift <= params["max_shift"]
+    return info, scores
+
+
+def test_full_config4():
+    """BASELINE config 4 at full size: 256 RNA pairs, len 2000, dot-bracket structures, max_shift=2
+    (921 GB of layers -> several HBM-budgeted chunks)."""
+    info, _ = _full_config_check(synth.rna_batch(256, 2000), dict(synth.RNA_PARAMS, max_shift=2), 8, 2)
+    assert info["cells"] == 256 * 9999 * 9999
+
+
+def test_full_config5_one_gpu_share():
+    """BASELINE config 5, one rank's share (1024 of the 8192 protein pairs, len 1024): 348 GB of
+    layers in two chunks; rank r of 8 would use seeds 1000 + r*1024 + p."""
+    info, scores = _full_config_check(synth.protein_batch(1024, 1024), dict(synth.PROTEIN_PARAMS), 16, 1)
+    assert info["cells"] == 1024 * 3073 * 3073
