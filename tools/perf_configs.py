@@ -6,7 +6,8 @@ from bialign_amd.batch import make_batch
 
 CASES = [
     ("cfg5 shape: 256 protein x1024 s=1 affine", synth.protein_batch(256, 1024), dict(synth.PROTEIN_PARAMS)),
-    ("cfg4 shape: 24 RNA x2000 s=2 affine", synth.rna_batch(24, 2000), dict(synth.RNA_PARAMS, max_shift=2)),
+    ("cfg4 full: 256 RNA x2000 s=2 affine", synth.rna_batch(256, 2000), dict(synth.RNA_PARAMS, max_shift=2)),
+    ("cfg5 one-GPU share: 1024 protein x1024 s=1", synth.protein_batch(1024, 1024), dict(synth.PROTEIN_PARAMS)),
     ("protein 512 x512 s=2 affine", synth.protein_batch(512, 512), dict(synth.PROTEIN_PARAMS, max_shift=2)),
     ("protein 512 x512 s=3 affine", synth.protein_batch(512, 512), dict(synth.PROTEIN_PARAMS, max_shift=3)),
     ("protein 1024 x512 s=0 affine", synth.protein_batch(1024, 512), dict(synth.PROTEIN_PARAMS, max_shift=0)),
