@@ -97,6 +97,7 @@ int64_t cells_of(int n, int m, int s) {
 
 struct bialign_engine {
   int device = 0;
+  int num_cu = 256;
   hipStream_t stream = nullptr;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
 };
@@ -113,7 +114,8 @@ struct bialign_batch {
   size_t lds_bytes = 0;                   // dynamic LDS of a one-wave workgroup
   size_t lds_base = 0, lds_per_wave = 0;  // team launches: lds_base + T * lds_per_wave
   DevBuf<PairDesc> d_pairs;
-  DevBuf<int32_t> d_order, d_s1, d_s2, d_layers, d_scores, d_tlen, d_complete, d_err;
+  DevBuf<int32_t> d_order, d_s1, d_s2, d_layers, d_scores, d_tlen, d_complete, d_err, d_prog;
+  int last_team = 1;  // waves per pair of the last fill launch (negative: cross-CU team)
   DevBuf<uint8_t> d_seq_a, d_cls_a, d_seq_b, d_cls_b, d_trace;
   int k1 = 0, k2 = 0;
   bialign_timing timing{};
@@ -149,60 +151,102 @@ size_t lds_need(int S, int NL, int team, int k1, int k2, int n, int m) {
   return (team * (ring_dw + nv * NCOL) + shared_dw) * 4 + 2 * npad + 2 * mpad;
 }
 
-template <int S, bool BETA_NONPOS, int T>
-int launch_fill_affine_t(const bialign_batch* b, const DeviceBatch& v, int first, int count) {
+// One launch shape: TW waves per workgroup, GW workgroups per pair (GW > 1 = cross-CU team).
+struct TeamShape {
+  int tw = 1, gw = 1;
+  int waves() const { return tw * gw; }
+};
+
+template <int S, bool BETA_NONPOS, int TW, bool XCU>
+int launch_fill_affine_t(bialign_batch* b, const DeviceBatch& v, int first, int count, int gw) {
   DeviceBatch w = v;
   w.order = v.order + first;
-  auto kern = fill_affine_kernel<S, BETA_NONPOS, T>;
-  const size_t lds = b->lds_base + (size_t)T * b->lds_per_wave;
+  w.team = gw;
+  auto kern = fill_affine_kernel<S, BETA_NONPOS, TW, XCU>;
+  const size_t lds = b->lds_base + (size_t)TW * b->lds_per_wave;
   if (lds > 64 * 1024)
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(kern, dim3(count), dim3(64 * T), lds, b->eng->stream, w);
+  if (XCU) {
+    if (b->d_prog.n < (size_t)count * 64) HIP_TRY(b->d_prog.alloc((size_t)count * 64));
+    HIP_TRY(hipMemsetAsync(b->d_prog.p, 0, (size_t)count * 64 * sizeof(int32_t), b->eng->stream));
+    w.prog = b->d_prog.p;
+  }
+  hipLaunchKernelGGL(kern, dim3(count * (XCU ? gw : 1)), dim3(64 * TW), lds, b->eng->stream, w);
   HIP_TRY(hipGetLastError());
   return BIALIGN_OK;
 }
 
-// Waves per pair (team size T).  More waves per pair = more waves per SIMD when a launch
-// has fewer pairs than the chip has wave slots worth filling (256 CUs x 4 SIMDs x 2).
-// Wave w trails wave w-1 by `lag` steps and wave 0 may lead wave T-1 by at most P - lag,
-// so T waves run without mutual waiting only if T*lag (+ margin) fits into P; every wave
-// should also own at least two strips.  Register budget: s<=1 kernels fit 2 waves/SIMD
-// (T<=8), s=2,3 need a whole SIMD's registers per wave (T<=4).
-int team_size(const bialign_batch* b, int first, int count) {
-  if (!b->affine) return 1;
+// Waves per pair.  More waves per pair = more waves per SIMD when a launch has fewer pairs than
+// the chip has wave slots worth filling (256 CUs x 4 SIMDs x 2).  Wave w trails wave w-1 by
+// `lag` steps and wave 0 may lead wave T-1 by at most P - lag, so T waves run without mutual
+// waiting only if T*lag (+ margin) fits into P; every wave should also own at least two strips.
+//  * in-workgroup teams (progress words in LDS): s<=1 kernels fit 2 waves/SIMD (TW<=8), s=2,3
+//    need a whole SIMD's registers per wave (TW<=4), s>=4 one wave; LDS <= 160 KB per workgroup.
+//  * cross-CU teams (one-wave workgroups, progress words in HBM, write-through stores): up to 32
+//    waves per pair, used when even the largest in-workgroup team leaves most SIMDs idle (few,
+//    long pairs).  Every workgroup of the launch must be resident at once (a wave spins on its
+//    predecessor), so the grid is capped by the LDS-limited residency of the device.
+TeamShape team_shape(const bialign_batch* b, int first, int count) {
+  TeamShape ts;
+  if (!b->affine) return ts;
   const int W = 2 * b->S + 1, R = 64 / W;
   const int lag = 2 * (R - 1) + 2 * ghost_blk(b->S) + 16;
-  int tmax = b->S <= 1 ? 8 : (b->S <= 3 ? 4 : 1);
+  int fit = 32;  // largest team the pairs of this launch allow
   for (int t = first; t < first + count; ++t) {
     const PairDesc& d = b->pairs[b->order[t]];
-    while (tmax > 1 && (d.P < std::max(256, tmax * lag + 64) || d.NS < 2 * tmax)) tmax >>= 1;
+    while (fit > 1 && (d.P < std::max(256, fit * lag + 64) || d.NS < 2 * fit)) fit >>= 1;
   }
-  while (tmax > 1 && b->lds_base + (size_t)tmax * b->lds_per_wave > 160 * 1024) tmax >>= 1;
-  if (const char* e = getenv("BIALIGN_TEAM")) {  // experiments / tests; never beyond the safe size
-    const int want = atoi(e);
-    int t = 1;
-    while (t * 2 <= want && t * 2 <= tmax) t *= 2;
-    return t;
+  int tw = std::min(fit, b->S <= 1 ? 8 : (b->S <= 3 ? 4 : 1));
+  while (tw > 1 && b->lds_base + (size_t)tw * b->lds_per_wave > 160 * 1024) tw >>= 1;
+  // one-wave workgroups resident per CU (LDS-limited; allocation granularity 1 KiB)
+  const size_t lds1 = (b->lds_base + b->lds_per_wave + 1023) / 1024 * 1024;
+  const int resident = b->eng->num_cu * (int)std::min<size_t>(8, (160 * 1024) / lds1);
+  int gw = b->S <= 3 ? fit : 1;
+  while (gw > 1 && (int64_t)count * gw > resident) gw >>= 1;
+
+  const char* e = getenv("BIALIGN_TEAM");  // experiments / tests: "N" in-workgroup, "xN" cross-CU
+  if (e && e[0] == 'x') {
+    int want = atoi(e + 1), g = 1;
+    while (g * 2 <= want && g * 2 <= gw) g *= 2;
+    ts.gw = g;
+    return ts;
   }
-  int t = 1;  // aim at two waves per SIMD over the whole chip, within 40 KB of LDS per two waves
-  while (t * 2 <= tmax && count * t * 2 <= 2048 + 1024) t *= 2;
-  return t;
+  if (e) {
+    int want = atoi(e), t = 1;
+    while (t * 2 <= want && t * 2 <= tw) t *= 2;
+    ts.tw = t;
+    return ts;
+  }
+  int t = 1;  // in-workgroup: aim at two waves per SIMD over the whole chip
+  while (t * 2 <= tw && count * t * 2 <= 2048 + 1024) t *= 2;
+  ts.tw = t;
+  // cross-CU: only when the chip would stay mostly empty and the team can be at least doubled
+  if (count * t <= 512 && gw >= 2 * t) {
+    int g = 1;
+    while (g * 2 <= gw && count * g * 2 <= 2048) g *= 2;
+    if (g >= 2 * t) { ts.tw = 1; ts.gw = g; }
+  }
+  return ts;
 }
 
 template <int S>
-int launch_fill_affine(const bialign_batch* b, const DeviceBatch& v, int first, int count) {
-  const int T = team_size(b, first, count);
+int launch_fill_affine(bialign_batch* b, const DeviceBatch& v, int first, int count) {
   if (b->prm.gap_opening_cost > 0)  // rare: general-beta algebra, one wave per pair
-    return launch_fill_affine_t<S, false, 1>(b, v, first, count);
+    return launch_fill_affine_t<S, false, 1, false>(b, v, first, count, 1);
+  const TeamShape ts = team_shape(b, first, count);
+  b->last_team = ts.waves() * (ts.gw > 1 ? -1 : 1);
+  if constexpr (S <= 3) {
+    if (ts.gw > 1) return launch_fill_affine_t<S, true, 1, true>(b, v, first, count, ts.gw);
+  }
   if constexpr (S <= 1) {
-    if (T == 8) return launch_fill_affine_t<S, true, 8>(b, v, first, count);
+    if (ts.tw == 8) return launch_fill_affine_t<S, true, 8, false>(b, v, first, count, 1);
   }
   if constexpr (S <= 3) {  // s >= 4 needs nearly all 512 registers of a SIMD lane: one wave per pair
-    if (T >= 4) return launch_fill_affine_t<S, true, 4>(b, v, first, count);
-    if (T >= 2) return launch_fill_affine_t<S, true, 2>(b, v, first, count);
+    if (ts.tw >= 4) return launch_fill_affine_t<S, true, 4, false>(b, v, first, count, 1);
+    if (ts.tw >= 2) return launch_fill_affine_t<S, true, 2, false>(b, v, first, count, 1);
   }
-  return launch_fill_affine_t<S, true, 1>(b, v, first, count);
+  return launch_fill_affine_t<S, true, 1, false>(b, v, first, count, 1);
 }
 
 template <int S>
@@ -220,7 +264,7 @@ int launch_traceback_affine(const bialign_batch* b, const DeviceBatch& v, int fi
 }
 
 template <int S>
-int launch_fill_linear(const bialign_batch* b, const DeviceBatch& v, int first, int count) {
+int launch_fill_linear(bialign_batch* b, const DeviceBatch& v, int first, int count) {
   DeviceBatch w = v;
   w.order = v.order + first;
   auto kern = fill_linear_kernel<S>;
@@ -246,7 +290,7 @@ int launch_traceback_linear(const bialign_batch* b, const DeviceBatch& v, int fi
   return BIALIGN_OK;
 }
 
-int launch_fill(const bialign_batch* b, const DeviceBatch& v, int first, int count) {
+int launch_fill(bialign_batch* b, const DeviceBatch& v, int first, int count) {
   if (b->affine) {
     switch (b->S) {
       case 0: return launch_fill_affine<0>(b, v, first, count);
@@ -351,6 +395,7 @@ int bialign_engine_create(int device, bialign_engine** out) {
                 prop.gcnArchName);
   auto* e = new bialign_engine();
   e->device = device;
+  e->num_cu = prop.multiProcessorCount;
   hipError_t err = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
   for (int i = 0; i < 4 && err == hipSuccess; ++i) err = hipEventCreate(&e->ev[i]);
   if (err != hipSuccess) {
@@ -540,6 +585,8 @@ int bialign_batch_run(bialign_batch* b, uint32_t flags) {
     b->timing.traceback_ms += t;
     b->timing.fill_launches += 1;
     b->timing.traceback_launches += 1;
+    b->timing.waves_per_pair = std::abs(b->last_team);
+    b->timing.cross_cu = b->last_team < 0;
   }
   HIP_TRY(hipStreamSynchronize(st));
   int32_t err = 0;

@@ -71,6 +71,8 @@ struct DeviceBatch {
   int32_t* trace_len;   // [npairs]
   int32_t* complete;    // [npairs]
   int32_t* errflag;     // [1] sticky device-side error (team protocol timeout)
+  int32_t* prog;        // cross-CU teams: [pairs in launch][64] progress words, zeroed per launch
+  int32_t team;         // cross-CU teams: workgroups (= waves) per pair
 };
 
 template <int S>
@@ -145,9 +147,8 @@ struct GhostFeed {
   // strip q = floor((h-aa)/P) and replays record  h + (q(T-1)+w)P - GOFF  (T waves per
   // pair, this one sweeps strips w, w+T, ...; T=1,w=0 gives h - GOFF).  blk_q / blk_rem
   // = h0 div / mod P, kept incrementally by the caller.
-  template <int T>
   __device__ static __forceinline__ void issue(const int32_t* lay, int h0, int blk_q, int blk_rem,
-                                               int P, int w, int GOFF, int rec_last, int lane,
+                                               int P, int T, int w, int GOFF, int rec_last, int lane,
                                                uint32_t lds_base) {
 #pragma unroll
     for (int r = 0; r < ROUNDS; ++r) {
@@ -224,16 +225,33 @@ struct BoolTag {
 // open(h,T) + v[h] <= v[T] + ... lets f_X, f_Y reuse f_M's max3:
 //   f_X(v) = max(v[X], beta + max3(v))     (exact for beta <= 0 only)
 //
-// TEAM = T waves per pair (one workgroup, T <= 16).  Wave w sweeps strips w, w+T,
-// w+2T, ... with the same record layout as a single wave would produce; the only
-// coupling is the ghost feed, which now replays records the previous wave of the
-// ring (w-1, or T-1 for wave 0) wrote.  Each wave publishes in an LDS word how many
-// of its steps have their stores acknowledged; a wave checks its predecessor's word
-// once per ghost block before prefetching.  Wave w>=1 therefore trails wave w-1 by
-// lag >= 2(R-1)+2*BLK+8 steps, and wave 0 may lead wave T-1 by at most P-lag: the
-// host picks T only if T*lag fits into P with room to spare (team_size()).
-template <int S, bool BETA_NONPOS, int T>
-__global__ void __launch_bounds__(64 * T) fill_affine_kernel(const DeviceBatch A) {
+// TEAM = T waves per pair.  Wave w sweeps strips w, w+T, w+2T, ... with the same
+// record layout as a single wave would produce; the only coupling is the ghost feed,
+// which now replays records the previous wave of the ring (w-1, or T-1 for wave 0)
+// wrote.  Each wave publishes in a progress word how many of its steps have their
+// stores acknowledged; a wave checks its predecessor's word once per ghost block
+// before prefetching.  Wave w>=1 therefore trails wave w-1 by lag >= 2(R-1)+2*BLK+8
+// steps, and wave 0 may lead wave T-1 by at most P-lag: the host picks T only if
+// T*lag fits into P with room to spare (team_shape()).
+//   XCU = false: the team is one workgroup of TW waves (T = TW), progress words in LDS.
+//   XCU = true : the team is A.team one-wave workgroups on any CUs / XCDs (T = A.team,
+//     block b -> pair b / T, wave b % T; all co-resident by construction of the grid).
+//     Per-XCD L2s are not coherent, so every layer store is write-through (sc1), the ghost
+//     DMAs and the progress words are sc1 accesses too, and a word is published only
+//     after the stores it covers have left the wave's vector-memory queue.
+typedef int v3i __attribute__((ext_vector_type(3)));
+
+template <bool XCU>
+__device__ __forceinline__ void store_chunk(int32_t* p, v4i v) {
+  if (XCU)
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+  else
+    *reinterpret_cast<v4i*>(p) = v;
+}
+
+template <int S, bool BETA_NONPOS, int TW, bool XCU>
+__global__ void __launch_bounds__(64 * TW) fill_affine_kernel(const DeviceBatch A) {
+  static_assert(!XCU || TW == 1, "cross-CU teams are built from one-wave workgroups");
   using G_ = Geo<S>;
   using R_ = Rec<S, 9>;
   constexpr int W = G_::W, R = G_::R, RR = G_::RR, PADB = G_::PADB;
@@ -241,10 +259,13 @@ __global__ void __launch_bounds__(64 * T) fill_affine_kernel(const DeviceBatch A
   constexpr int NV = XR * W, ND = R_::ND, NCH4 = R_::NCH4, TAIL = R_::TAIL, RECDW = R_::RECDW;
   extern __shared__ __align__(16) int32_t smem[];
 
-  const PairDesc pd = A.pairs[A.order[blockIdx.x]];
+  const int T = XCU ? A.team : TW;                       // team size
+  const int slot = XCU ? blockIdx.x / T : blockIdx.x;     // pair of this launch
+  const PairDesc pd = A.pairs[A.order[slot]];
   const int n = pd.n, m = pd.m, P = pd.P;
   const int L = threadIdx.x & 63;
-  const int w = T == 1 ? 0 : __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave in team
+  const int wl = TW == 1 ? 0 : __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave in workgroup
+  const int w = XCU ? (int)(blockIdx.x - slot * T) : wl;                              // wave in team
   const int il = L / W, aa = L - il * W;
   const bool live = L < R * W;
   const bool ghost = (il == 0);
@@ -255,10 +276,10 @@ __global__ void __launch_bounds__(64 * T) fill_affine_kernel(const DeviceBatch A
   // ---- LDS carve-up: per wave a ghost ring and an exchange array; shared: progress
   //      words, score tables, sequence codes
   using GF = GhostFeed<S, 9>;
-  v4i* ring = reinterpret_cast<v4i*>(smem + w * GF::RING_DW);   // ghost-row ring, two halves
-  int32_t* xch = smem + T * GF::RING_DW + w * (NV * NCOL);      // [NV][NCOL] exchange array
-  volatile int32_t* prog = smem + T * (GF::RING_DW + NV * NCOL); // [16] steps with stores acknowledged
-  int32_t* s1 = smem + T * (GF::RING_DW + NV * NCOL) + 16;      // [k1*k1]
+  v4i* ring = reinterpret_cast<v4i*>(smem + wl * GF::RING_DW);   // ghost-row ring, two halves
+  int32_t* xch = smem + TW * GF::RING_DW + wl * (NV * NCOL);     // [NV][NCOL] exchange array
+  volatile int32_t* prog_lds = smem + TW * (GF::RING_DW + NV * NCOL);  // [16] (in-workgroup teams)
+  int32_t* s1 = smem + TW * (GF::RING_DW + NV * NCOL) + 16;      // [k1*k1]
   int32_t* s2 = s1 + k1 * k1;                                   // [k2*k2]
   const int npad = (n + 3) & ~3, mpad = (m + 2 * PADB + 3) & ~3;
   uint8_t* sa = reinterpret_cast<uint8_t*>(s2 + k2 * k2);  // seq A codes, [i-1]
@@ -266,15 +287,15 @@ __global__ void __launch_bounds__(64 * T) fill_affine_kernel(const DeviceBatch A
   uint8_t* sb = ca + npad;                                  // seq B codes, [j-1+PADB]
   uint8_t* cb = sb + mpad;                                  // cls B,       [l-1+PADB]
 
-  for (int t = threadIdx.x; t < T * (GF::RING_DW + NV * NCOL); t += 64 * T) smem[t] = SENT;
-  if (threadIdx.x < 16) prog[threadIdx.x] = 0;
-  for (int t = threadIdx.x; t < k1 * k1; t += 64 * T) s1[t] = A.s1[t];
-  for (int t = threadIdx.x; t < k2 * k2; t += 64 * T) s2[t] = A.s2[t];
-  for (int t = threadIdx.x; t < n; t += 64 * T) {
+  for (int t = threadIdx.x; t < TW * (GF::RING_DW + NV * NCOL); t += 64 * TW) smem[t] = SENT;
+  if (threadIdx.x < 16) prog_lds[threadIdx.x] = 0;
+  for (int t = threadIdx.x; t < k1 * k1; t += 64 * TW) s1[t] = A.s1[t];
+  for (int t = threadIdx.x; t < k2 * k2; t += 64 * TW) s2[t] = A.s2[t];
+  for (int t = threadIdx.x; t < n; t += 64 * TW) {
     sa[t] = A.seq_a[pd.seq_a + t];
     ca[t] = A.cls_a[pd.seq_a + t];
   }
-  for (int t = threadIdx.x; t < m + 2 * PADB; t += 64 * T) {
+  for (int t = threadIdx.x; t < m + 2 * PADB; t += 64 * TW) {
     const int src = t - PADB;
     const bool ok = src >= 0 && src < m;
     sb[t] = ok ? A.seq_b[pd.seq_b + src] : 0;
@@ -329,18 +350,29 @@ __global__ void __launch_bounds__(64 * T) fill_affine_kernel(const DeviceBatch A
 #pragma unroll
   for (int d = 0; d < ND; ++d) ghostM[d] = SENT;
   const uint32_t ring_lds = __builtin_amdgcn_readfirstlane(
-      (uint32_t)(uintptr_t)(__attribute__((address_space(3))) int32_t*)smem) + w * GF::RING_DW * 4;
+      (uint32_t)(uintptr_t)(__attribute__((address_space(3))) int32_t*)smem) + wl * GF::RING_DW * 4;
 
   // ---- team protocol (T > 1): partner progress needed before prefetching the ghost
   //      block whose last local step is h_last
   int blk_q = 0, blk_rem = 0;  // (next block start) div / mod P
   bool team_failed = false;
+  int32_t* const prog_glb = XCU ? A.prog + (int64_t)slot * 64 : nullptr;
+  auto prog_get = [&](int idx) __attribute__((always_inline)) -> int {
+    if (XCU) return __hip_atomic_load(prog_glb + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return prog_lds[idx];
+  };
+  auto prog_put = [&](int v) __attribute__((always_inline)) {  // lane 0 only
+    if (XCU)
+      __hip_atomic_store(prog_glb + w, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else
+      prog_lds[w] = v;
+  };
   auto wait_partner = [&](int h_last) __attribute__((always_inline)) {
-    if (T == 1 || team_failed) return;
+    if ((!XCU && TW == 1) || T == 1 || team_failed) return;
     const int src = w == 0 ? T - 1 : w - 1;
     const int need = h_last + 2 * (R - 1) + 1 - (w == 0 ? P : 0);
     // bounded spin: a protocol bug must surface as an error, never as a hung GPU
-    for (int spin = 0; prog[src] < need; ++spin) {
+    for (int spin = 0; prog_get(src) < need; ++spin) {
       if (spin > (1 << 20)) {  // ~0.5 s; then fail fast: no further waits, host reports the error
         if (L == 0) atomicExch(A.errflag, 1);
         team_failed = true;
@@ -352,7 +384,7 @@ __global__ void __launch_bounds__(64 * T) fill_affine_kernel(const DeviceBatch A
   auto prefetch_block = [&](int h0, int half) __attribute__((always_inline)) {
     // h0 = first local step of the block; blk_q/blk_rem describe h0
     wait_partner(h0 + GF::BLK - 1);
-    GF::template issue<T>(lay, h0, blk_q, blk_rem, P, w, GOFF, rec_last, L, ring_lds + half * GF::SLOTS * 16);
+    GF::issue(lay, h0, blk_q, blk_rem, P, T, w, GOFF, rec_last, L, ring_lds + half * GF::SLOTS * 16);
     blk_rem += GF::BLK;
     if (blk_rem >= P) { blk_rem -= P; ++blk_q; }
   };
@@ -373,7 +405,7 @@ __global__ void __launch_bounds__(64 * T) fill_affine_kernel(const DeviceBatch A
     const int gt = g & (GF::BLK - 1), ghalf = (g / GF::BLK) & 1;
     if (gt == 0) {
       GF::wait_block();
-      if (T > 1 && L == 0) prog[w] = g - 8;  // <= 40 vector-memory ops pending = < 6 steps of stores
+      if ((XCU || TW > 1) && L == 0) prog_put(g - 8);  // <= 40 vector-memory ops pending = < 6 steps of stores
       prefetch_block(g + GF::BLK, ghalf ^ 1);
     }
     GF::fetch(ghostM, ring + ghalf * GF::SLOTS, gt, aa);
@@ -416,7 +448,7 @@ __global__ void __launch_bounds__(64 * T) fill_affine_kernel(const DeviceBatch A
     const int rec = g + rec_base;  // lanes of two strips (straddling steps) hit two records
     const bool do_store = BIALIGN_EXP != 1 &&
                           (INTERIOR || __builtin_amdgcn_ballot_w64(tile_act && !ghost) != 0) &&
-                          (T == 1 || rec <= rec_last);
+                          ((!XCU && TW == 1) || rec <= rec_last);
     int32_t* const dst = BIALIGN_EXP == 2
                              ? A.layers + ((int64_t)(blockIdx.x & 255) << 18) + (int64_t)(g & 31) * RECDW
                              : lay + (int64_t)rec * RECDW;
@@ -505,12 +537,18 @@ __global__ void __launch_bounds__(64 * T) fill_affine_kernel(const DeviceBatch A
           if (4 * c + 3 >= bb * 9 && 4 * c + 3 < (bb + 1) * 9) {  // chunk c completes with this point
             v4i v;
             v.x = outv[4 * c]; v.y = outv[4 * c + 1]; v.z = outv[4 * c + 2]; v.w = outv[4 * c + 3];
-            *reinterpret_cast<v4i*>(dst + c * 256 + L * 4) = v;
+            store_chunk<XCU>(dst + c * 256 + L * 4, v);
           }
         }
         if (bb == W - 1) {
 #pragma unroll
-          for (int t = 0; t < TAIL; ++t) dst[NCH4 * 256 + L * TAIL + t] = outv[4 * NCH4 + t];
+          for (int t = 0; t < TAIL; ++t) {
+            if (XCU)
+              __hip_atomic_store(dst + NCH4 * 256 + L * TAIL + t, outv[4 * NCH4 + t], __ATOMIC_RELAXED,
+                                 __HIP_MEMORY_SCOPE_AGENT);
+            else
+              dst[NCH4 * 256 + L * TAIL + t] = outv[4 * NCH4 + t];
+          }
         }
       }
 
@@ -615,9 +653,9 @@ __global__ void __launch_bounds__(64 * T) fill_affine_kernel(const DeviceBatch A
       ++g;
     }
   }
-  if (T > 1) {  // everything this wave wrote is acknowledged: release the partner for good
+  if (XCU || TW > 1) {  // everything this wave wrote is acknowledged: release the partner for good
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (L == 0) prog[w] = 0x7fffffff;
+    if (L == 0) prog_put(0x7fffffff);
   }
 }
 
@@ -806,7 +844,7 @@ __global__ void __launch_bounds__(64) fill_linear_kernel(const DeviceBatch A) {
     const int gt = g & (GF::BLK - 1), ghalf = (g / GF::BLK) & 1;
     if (gt == 0) {
       GF::wait_block();
-      GF::template issue<1>(lay, (g / GF::BLK + 1) * GF::BLK, 0, 0, P, 0, GOFF, pd.G - 1, L,
+      GF::issue(lay, (g / GF::BLK + 1) * GF::BLK, 0, 0, P, 1, 0, GOFF, pd.G - 1, L,
                             ring_lds + (ghalf ^ 1) * GF::SLOTS * 16);
     }
     GF::fetch(ghostM, ring + ghalf * GF::SLOTS, gt, aa);

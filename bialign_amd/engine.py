@@ -113,7 +113,8 @@ class Batch:
         t = _lib.Timing()
         check(lib.bialign_batch_get_timing(self._h, ctypes.byref(t)))
         return dict(fill_ms=t.fill_ms, traceback_ms=t.traceback_ms,
-                    fill_launches=t.fill_launches, traceback_launches=t.traceback_launches)
+                    fill_launches=t.fill_launches, traceback_launches=t.traceback_launches,
+                    waves_per_pair=t.waves_per_pair, cross_cu=bool(t.cross_cu))
 
     def scores(self):
         out = np.empty(self.npairs, dtype=np.int32)

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define BIALIGN_ABI_VERSION 2
+#define BIALIGN_ABI_VERSION 3
 
 #define BIALIGN_OK 0
 #define BIALIGN_E_INVALID (-1)     /* bad argument (message says which) */
@@ -100,6 +100,8 @@ typedef struct bialign_timing {
   double traceback_ms; /* ... of the traceback (or score-only) kernels */
   int32_t fill_launches;
   int32_t traceback_launches;
+  int32_t waves_per_pair; /* team size of the last fill launch (team sweep) */
+  int32_t cross_cu;       /* 1 if that team was spread over one-wave workgroups */
 } bialign_timing;
 
 int bialign_abi_version(void);

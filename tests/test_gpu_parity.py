@@ -25,7 +25,7 @@ def gpu_solve(rec, layers=False):
     b.run()
     score = int(b.scores()[0])
     traces, ok = b.traces()
-    out = dict(score=score, trace=trace_codes_to_columns(traces[0]), complete=bool(ok[0]))
+    out = dict(score=score, trace=trace_codes_to_columns(traces[0]), complete=bool(ok[0]), timing=b.timing())
     if layers:
         out["layers"] = b.dump_layers(0)
     b.close()
@@ -80,6 +80,7 @@ def test_full_layers_vs_oracle(n, m, s, seed):
     rv = oracle.band_values(ref["layers"], n, m, s)
     for g, e in zip(gv, rv):
         np.testing.assert_array_equal(g, e)
+    return got["timing"]
 
 
 def test_ragged_batch_vs_oracle():
@@ -105,13 +106,24 @@ def test_ragged_batch_vs_oracle():
         b.close()
 
 
-@pytest.mark.parametrize("n,m,s,seed,team", [(300, 300, 1, 21, 2), (130, 420, 1, 22, 2), (420, 330, 0, 23, 2),
+@pytest.mark.parametrize("n,m,s,seed,team", [(300, 300, 1, 21, 2), (130, 420, 1, 22, 2), (420, 400, 0, 23, 2),
                                               (330, 650, 1, 24, 8), (170, 400, 1, 25, 4), (100, 300, 2, 26, 4),
                                               (80, 300, 3, 27, 4)])
 def test_team_sweep_full_layers(n, m, s, seed, team, monkeypatch):
     """T waves per pair on interleaved strips (forced): every layer cell, trace and score."""
     monkeypatch.setenv("BIALIGN_TEAM", str(team))
-    test_full_layers_vs_oracle(n, m, s, seed)
+    t = test_full_layers_vs_oracle(n, m, s, seed)
+    assert t["waves_per_pair"] == team and not t["cross_cu"]
+
+
+@pytest.mark.parametrize("n,m,s,seed,team", [(330, 650, 1, 31, 8), (700, 1300, 1, 32, 16), (130, 420, 1, 33, 2),
+                                              (200, 500, 2, 34, 8), (420, 400, 0, 35, 2), (90, 400, 3, 36, 4)])
+def test_cross_cu_team_full_layers(n, m, s, seed, team, monkeypatch):
+    """The team spread over one-wave workgroups on different CUs / XCDs (write-through stores,
+    progress words in HBM): every layer cell, trace and score."""
+    monkeypatch.setenv("BIALIGN_TEAM", "x%d" % team)
+    t = test_full_layers_vs_oracle(n, m, s, seed)
+    assert t["waves_per_pair"] == team and t["cross_cu"]
 
 
 def test_team_sweep_batch_matches_single_wave(monkeypatch):
