@@ -68,9 +68,17 @@ def main():
 
     import torch
     import torch.distributed as dist
-    torch.cuda.set_device(local_rank)
+    # BIALIGN_BENCH_REHEARSE=1: rehearse the N>1 flow on a box with fewer GPUs than ranks
+    # (ranks share devices, collectives over gloo) -- for testing the script, never for numbers.
+    rehearse = os.environ.get("BIALIGN_BENCH_REHEARSE") == "1"
+    device = local_rank % torch.cuda.device_count() if rehearse else local_rank
+    torch.cuda.set_device(device)
+    cdev = torch.device("cpu") if rehearse else torch.device("cuda", device)  # where collectives run
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device))
 
     from bialign_amd import synth
     from bialign_amd.batch import make_batch
@@ -78,7 +86,7 @@ def main():
 
     params = dict(synth.PROTEIN_PARAMS, max_shift=args.max_shift)
     pairs = synth.protein_batch(args.pairs, args.length, seed0=1000 + rank * args.pairs)
-    engine = Engine(local_rank)
+    engine = Engine(device)
     batch = make_batch(pairs, params, engine=engine)  # inputs now resident in HBM
     info = batch.info
 
@@ -110,10 +118,10 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-        tot = torch.tensor([info["cells"], info["npairs"]], dtype=torch.int64, device="cuda")
+        tot = torch.tensor([info["cells"], info["npairs"]], dtype=torch.int64, device=cdev)
         dist.all_reduce(tot)
         total_cells, total_pairs = int(tot[0].item()), int(tot[1].item())
     else:
@@ -132,6 +140,7 @@ def main():
         line = {
             "metric": "giga-DP-cells/sec", "value": total_cells * args.steps / elapsed / 1e9,
             "unit": "Gcells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            **({"rehearsal": "ranks share GPUs, gloo collectives: NOT a measurement"} if rehearse else {}),
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "int32", "data": "synthetic",
             "pairs_per_s": total_pairs * args.steps / elapsed,
