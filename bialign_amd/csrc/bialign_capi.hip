@@ -368,6 +368,13 @@ int launch_dump_any(const bialign_batch* b, const DeviceBatch& v, int pid, int32
   return fail(BIALIGN_E_UNSUPPORTED, "no dump kernel for affine=%d max_shift=%d", b->affine, b->S);
 }
 
+int check_device_error(const bialign_batch* b) {
+  int32_t err = 0;
+  HIP_TRY(hipMemcpy(&err, b->d_err.p, sizeof err, hipMemcpyDeviceToHost));
+  if (err) return fail(BIALIGN_E_DEVICE, "fill kernel: team hand-off timed out (device error flag %d)", err);
+  return BIALIGN_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -591,9 +598,8 @@ int bialign_batch_run(bialign_batch* b, uint32_t flags) {
     b->timing.cross_cu = b->last_team < 0;
   }
   HIP_TRY(hipStreamSynchronize(st));
-  int32_t err = 0;
-  HIP_TRY(hipMemcpy(&err, b->d_err.p, sizeof err, hipMemcpyDeviceToHost));
-  if (err) return fail(BIALIGN_E_DEVICE, "fill kernel: team hand-off timed out (device error flag %d)", err);
+  int rc_err = check_device_error(b);
+  if (rc_err) return rc_err;
   b->ran = true;
   b->ran_trace = do_trace;
   return BIALIGN_OK;
@@ -630,12 +636,10 @@ int bialign_batch_dump_layers(bialign_batch* b, int32_t pair, int32_t* out) {
   if (pair < 0 || pair >= b->npairs) return fail(BIALIGN_E_INVALID, "pair %d out of range", pair);
   HIP_TRY(hipSetDevice(b->eng->device));
   hipStream_t st = b->eng->stream;
-  // one-pair launch: order entry = pair; the pair keeps its chunk-relative layer_off
-  DevBuf<int32_t> d_one;
-  HIP_TRY(d_one.upload(&pair, 1, st));
+  // one-pair launch out of the regular launch order (team shape and layer offset are the pair's own)
+  const int pos = (int)(std::find(b->order.begin(), b->order.end(), pair) - b->order.begin());
   DeviceBatch v = b->view();
-  v.order = d_one.p;
-  int rc = launch_fill(b, v, 0, 1);
+  int rc = launch_fill(b, v, pos, 1);
   if (rc) return rc;
   const PairDesc& d = b->pairs[pair];
   const int W = 2 * b->S + 1;
@@ -647,7 +651,7 @@ int bialign_batch_dump_layers(bialign_batch* b, int32_t pair, int32_t* out) {
   HIP_TRY(hipMemcpyAsync(out, d_out.p, elems * sizeof(int32_t), hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
   b->ran = false;  // the resident chunk's layers were overwritten
-  return BIALIGN_OK;
+  return check_device_error(b);
 }
 
 }  // extern "C"

@@ -173,3 +173,20 @@ def test_fuzz_against_oracle():
             np.testing.assert_array_equal(g, e, err_msg=str((case, params)))
         checked += 1
     assert checked == 160
+
+
+def test_dump_layers_of_any_pair_in_a_batch():
+    """dump_layers re-fills one pair with that pair's own launch shape, wherever it sits in the batch."""
+    from oracle import oracle
+    from bialign_amd.batch import make_batch
+    shapes = [(30, 20), (400, 420), (12, 12), (90, 300)]
+    pairs = [synth.protein_pair(700 + t, n, m) for t, (n, m) in enumerate(shapes)]
+    params = dict(synth.PROTEIN_PARAMS)
+    b = make_batch(pairs, params)
+    b.run()
+    for t in (1, 3, 0):
+        n, m = shapes[t]
+        ref = oracle.solve(*pairs[t], params, want_trace=False)
+        for g, e in zip(oracle.band_values(b.dump_layers(t), n, m, 1), oracle.band_values(ref["layers"], n, m, 1)):
+            np.testing.assert_array_equal(g, e)
+    b.close()
