@@ -67,6 +67,10 @@ def test_medium_traces(rec):
                                          (61, 64, 3, 8), (257, 129, 1, 9), (40, 50, 4, 10), (33, 45, 5, 11)])
 def test_full_layers_vs_oracle(n, m, s, seed):
     """Several strips / ragged shapes: every layer cell against the oracle."""
+    full_layers_check(n, m, s, seed)
+
+
+def full_layers_check(n, m, s, seed):
     from oracle import oracle
     sa, sb, ta, tb = synth.protein_pair(seed, n, m)
     params = dict(synth.PROTEIN_PARAMS, max_shift=s)
@@ -112,7 +116,7 @@ def test_ragged_batch_vs_oracle():
 def test_team_sweep_full_layers(n, m, s, seed, team, monkeypatch):
     """T waves per pair on interleaved strips (forced): every layer cell, trace and score."""
     monkeypatch.setenv("BIALIGN_TEAM", str(team))
-    t = test_full_layers_vs_oracle(n, m, s, seed)
+    t = full_layers_check(n, m, s, seed)
     assert t["waves_per_pair"] == team and not t["cross_cu"]
 
 
@@ -122,7 +126,7 @@ def test_cross_cu_team_full_layers(n, m, s, seed, team, monkeypatch):
     """The team spread over one-wave workgroups on different CUs / XCDs (write-through stores,
     progress words in HBM): every layer cell, trace and score."""
     monkeypatch.setenv("BIALIGN_TEAM", "x%d" % team)
-    t = test_full_layers_vs_oracle(n, m, s, seed)
+    t = full_layers_check(n, m, s, seed)
     assert t["waves_per_pair"] == team and t["cross_cu"]
 
 
