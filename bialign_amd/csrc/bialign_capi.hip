@@ -201,8 +201,8 @@ TeamShape team_shape(const bialign_batch* b, int first, int count) {
   while (tw > 1 && b->lds_base + (size_t)tw * b->lds_per_wave > 160 * 1024) tw >>= 1;
   // one-wave workgroups resident per CU (LDS-limited; allocation granularity 1 KiB)
   const size_t lds1 = (b->lds_base + b->lds_per_wave + 1023) / 1024 * 1024;
-  // ... and register-limited: the s<=1 kernels allow 3 waves per SIMD, s=2,3 one wave per SIMD
-  const size_t by_regs = b->S <= 1 ? 8 : 4;
+  // ... and register-limited: the s<=2 kernels allow >= 2 waves per SIMD, s=3 one wave per SIMD
+  const size_t by_regs = b->S <= 2 ? 8 : 4;
   const int resident = b->eng->num_cu * (int)std::min<size_t>(by_regs, (160 * 1024) / lds1);
   int gw = b->S <= 3 ? fit : 1;
   while (gw > 1 && (int64_t)count * gw > resident) gw >>= 1;

@@ -410,23 +410,26 @@ __global__ void __launch_bounds__(64 * TW) fill_affine_kernel(const DeviceBatch 
     }
     GF::fetch(ghostM, ring + ghalf * GF::SLOTS, gt, aa);
 
-    // ---- 1. exchange reads: what the three source lanes published last step
+    // ---- 1. exchange reads: what the three source lanes published last step.  Rows of band
+    //         column r are first needed by point r-1, so they are fetched two points ahead
+    //         (all of them up front for W <= 3): a sliding window keeps registers flat in W.
     int inA[W][4], inB[W][8], inC[W][8];
+    auto read_rows = [&](int r) __attribute__((always_inline)) {
 #pragma unroll
-    for (int bb = 0; bb < W; ++bb) {
+      for (int x = 0; x < 4; ++x) inA[r][x] = xch[(r * XR + x) * NCOL + colLW];
 #pragma unroll
-      for (int x = 0; x < 4; ++x) inA[bb][x] = xch[(bb * XR + x) * NCOL + colLW];
-#pragma unroll
-      for (int x = 0; x < 8; ++x) inB[bb][x] = xch[(bb * XR + 4 + x) * NCOL + colLW1];
+      for (int x = 0; x < 8; ++x) inB[r][x] = xch[(r * XR + 4 + x) * NCOL + colLW1];
       // lane L-1 = (i, a-1) hands its values over in registers: one DPP wave shift,
       // and the sentinel where a-1 leaves the band
 #pragma unroll
       for (int x = 0; x < 8; ++x) {
         // (lane 0 reads out of range -> 0 with bound_ctrl; it is an a_first lane anyway)
-        const int nb = __builtin_amdgcn_mov_dpp(pubC[bb][x], 0x138 /* wave_shr:1 */, 0xf, 0xf, true);
-        inC[bb][x] = a_first ? SENT : nb;
+        const int nb = __builtin_amdgcn_mov_dpp(pubC[r][x], 0x138 /* wave_shr:1 */, 0xf, 0xf, true);
+        inC[r][x] = a_first ? SENT : nb;
       }
-    }
+    };
+    read_rows(0);
+    if (W > 1) read_rows(W > 1 ? 1 : 0);
 
     // ---- 2. score inputs of this column (pyx:260-261; LOOKUP form)
     const int jc = INTERIOR ? jj : min(max(jj, 0), m + 1);
@@ -458,6 +461,7 @@ __global__ void __launch_bounds__(64 * TW) fill_affine_kernel(const DeviceBatch 
     int h2y[3] = {SENT, SENT, SENT};  // H2[U][Y] of point bb-1 (same step, same lane)
 #pragma unroll
     for (int bb = 0; bb < W; ++bb) {
+      if (bb + 2 < W) read_rows(bb + 2 < W ? bb + 2 : 0);
       const int l = jj + bb - S;
       const bool act = INTERIOR ? true : (tile_act && l >= 0 && l <= m);
       const int mu2v = mu2[bb];
@@ -608,23 +612,24 @@ __global__ void __launch_bounds__(64 * TW) fill_affine_kernel(const DeviceBatch 
       for (int v = 0; v < 3; ++v) selfv[1 + v][bb] = H3[0][v];
 #pragma unroll
       for (int u = 0; u < 3; ++u) h2y[u] = H2[u][0];
-    }
 
-    // ---- 4. delay lines
-#pragma unroll
-    for (int bb = 0; bb < W; ++bb) {
+      // delay lines: index bb (bb-1 for GXM/GXX) has served its last consumer of this step
       dA2[0][bb] = dA1[0][bb];
       dA2[1][bb] = dA1[1][bb];
       dA1[0][bb] = inA[bb][0];
       dA1[1][bb] = inA[bb][1];
-      dAx[0][bb] = inA[bb][2];
-      dAx[1][bb] = inA[bb][3];
       dB[0][bb] = inB[bb][0];
 #pragma unroll
       for (int v = 0; v < 3; ++v) dB[1 + v][bb] = inB[bb][2 + v];
       dC[0][bb] = inC[bb][0];
       dC[1][bb] = inC[bb][1];
+      if (bb >= 1) {
+        dAx[0][bb >= 1 ? bb - 1 : 0] = inA[bb >= 1 ? bb - 1 : 0][2];
+        dAx[1][bb >= 1 ? bb - 1 : 0] = inA[bb >= 1 ? bb - 1 : 0][3];
+      }
     }
+    dAx[0][W - 1] = inA[W - 1][2];
+    dAx[1][W - 1] = inA[W - 1][3];
 
     // ---- 6. advance
     ++jj;
