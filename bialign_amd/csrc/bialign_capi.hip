@@ -220,8 +220,18 @@ TeamShape team_shape(const bialign_batch* b, int first, int count) {
     ts.tw = t;
     return ts;
   }
-  int t = 1;  // in-workgroup: aim at two waves per SIMD over the whole chip
-  while (t * 2 <= tw && count * t * 2 <= 2048 + 1024) t *= 2;
+  // in-workgroup: the smallest team that (nearly) maximises the waves running at once, given
+  // how many workgroups of that size a CU holds (LDS, registers)
+  const int waves_cu_regs = b->S <= 1 ? 12 : (b->S == 2 ? 8 : 4);
+  auto concurrent = [&](int t) {
+    const size_t lds = (b->lds_base + (size_t)t * b->lds_per_wave + 1023) / 1024 * 1024;
+    const int wg_cu = (int)std::min<size_t>((160 * 1024) / lds, (size_t)(waves_cu_regs / t));
+    return std::min<int64_t>((int64_t)count * t, (int64_t)b->eng->num_cu * wg_cu * t);
+  };
+  int64_t best = 0;
+  for (int c = 1; c <= tw; c *= 2) best = std::max(best, concurrent(c));
+  int t = 1;
+  while (t < tw && concurrent(t) * 100 < best * 95) t *= 2;
   ts.tw = t;
   // cross-CU: only when the chip would stay mostly empty and the team can be at least doubled
   if (count * t <= 512 && gw >= 2 * t) {
