@@ -3,19 +3,21 @@
 // Mapping of the 4-D lattice onto a wavefront (see DESIGN.md for the derivation)
 // ------------------------------------------------------------------------------
 // Lattice point q = (i,j,k,l), band coordinates a = k-i, b = l-j in [-s,s],
-// W = 2s+1.  One 64-lane wave owns one pair.  Lane L = il*W + aa holds the
-// (row, a) pair  i = strip*RR + il - 1,  a = aa - s  for R = 64/W lane rows, of
-// which il = 0 is a *ghost* row (the last row of the previous strip, re-read
-// from HBM) and il = 1..R-1 are the RR real rows of the strip.  At global step
-// g the lane works on column  j = (g - 2*il - aa) mod P  and computes the W
-// lattice points b = -s..s of that (i,j,a): all nine affine states each.
-// With this skew every predecessor named by the reference's case generator
-// (pyx:255-296) was computed 1, 2 or 3 steps earlier by lane L-1, L-W+1, L-W or
-// by the lane itself.  Values cross lanes through a per-wave LDS exchange array
-// (written at the end of a step, read at the start of the next one; lane L-1's
-// values travel by a DPP wave shift instead); values
-// needed 2 or 3 steps later wait in registers.  Nothing crosses waves, so the
-// sweep needs no barrier.
+// W = 2s+1.  A 64-lane wave sweeps strips of rows of one pair (one wave per pair,
+// or a team of waves on interleaved strips, see fill_affine_kernel).  Lane
+// L = il*W + aa holds the (row, a) pair  i = strip*RR + il - 1,  a = aa - s  for
+// R = 64/W lane rows, of which il = 0 is a *ghost* row (the last row of the
+// previous strip, replayed from the layers already in HBM) and il = 1..R-1 are
+// the RR real rows of the strip.  At step g the lane works on column
+// j = (g - 2*il - aa) mod P  and computes the W lattice points b = -s..s of that
+// (i,j,a): all nine affine states each.  With this skew every predecessor named
+// by the reference's case generator (pyx:255-296) was computed 1, 2 or 3 steps
+// earlier by lane L-1, L-W+1, L-W or by the lane itself.  Values for rows i+1
+// cross lanes through a per-wave LDS exchange array (written when a point is
+// done, read at the start of the next step); lane L-1's values travel by a DPP
+// wave shift; values needed 2 or 3 steps later wait in registers.  Within a wave
+// the LDS is in-order, so the sweep needs no barrier; waves of a team only meet
+// through the layers in HBM and one progress word each.
 //
 // Algebra (bit-exact regrouping of the reference's 15 cases per state, SURVEY.md
 // section 7 / Appendix A).  Halves: Y=(0,1) X=(1,0) M=(1,1), state = 3*hU + hV
