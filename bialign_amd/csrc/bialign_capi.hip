@@ -113,6 +113,7 @@ struct bialign_batch {
   int64_t cells = 0, trace_bytes = 0, max_chunk_dwords = 0;
   size_t lds_bytes = 0;                   // dynamic LDS of a one-wave workgroup
   size_t lds_base = 0, lds_per_wave = 0;  // team launches: lds_base + T * lds_per_wave
+  size_t lds_trace = 0;                   // tracebacks: score tables + sequence codes
   DevBuf<PairDesc> d_pairs;
   DevBuf<int32_t> d_order, d_s1, d_s2, d_layers, d_scores, d_tlen, d_complete, d_err, d_prog;
   int last_team = 1;  // waves per pair of the last fill launch (negative: cross-CU team)
@@ -267,8 +268,11 @@ int launch_traceback_affine(const bialign_batch* b, const DeviceBatch& v, int fi
   DeviceBatch w = v;
   w.order = v.order + first;
   const int blocks = count;  // one wave per pair
+  if (b->lds_trace > 64 * 1024)
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(traceback_affine_kernel<S, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_trace));
   if (do_trace)
-    hipLaunchKernelGGL((traceback_affine_kernel<S, true>), dim3(blocks), dim3(64), 0, b->eng->stream, w, count);
+    hipLaunchKernelGGL((traceback_affine_kernel<S, true>), dim3(blocks), dim3(64), b->lds_trace, b->eng->stream, w, count);
   else
     hipLaunchKernelGGL((traceback_affine_kernel<S, false>), dim3(blocks), dim3(64), 0, b->eng->stream, w, count);
   HIP_TRY(hipGetLastError());
@@ -294,8 +298,11 @@ int launch_traceback_linear(const bialign_batch* b, const DeviceBatch& v, int fi
   DeviceBatch w = v;
   w.order = v.order + first;
   const int blocks = count;  // one wave per pair
+  if (b->lds_trace > 64 * 1024)
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(traceback_linear_kernel<S, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_trace));
   if (do_trace)
-    hipLaunchKernelGGL((traceback_linear_kernel<S, true>), dim3(blocks), dim3(64), 0, b->eng->stream, w, count);
+    hipLaunchKernelGGL((traceback_linear_kernel<S, true>), dim3(blocks), dim3(64), b->lds_trace, b->eng->stream, w, count);
   else
     hipLaunchKernelGGL((traceback_linear_kernel<S, false>), dim3(blocks), dim3(64), 0, b->eng->stream, w, count);
   HIP_TRY(hipGetLastError());
@@ -495,6 +502,8 @@ int bialign_batch_create(bialign_engine* eng, const bialign_params* prm, const b
     tot_b = std::max<int64_t>(tot_b, pr->off_b[p] + m);
     b->lds_bytes = std::max(b->lds_bytes, lds_need(S, b->NL, 1, sc->k1, sc->k2, n, m));
     b->lds_base = std::max(b->lds_base, lds_need(S, b->NL, 0, sc->k1, sc->k2, n, m));
+    b->lds_trace = std::max<size_t>(b->lds_trace, ((size_t)sc->k1 * sc->k1 + (size_t)sc->k2 * sc->k2) * 4 +
+                                                      2 * (size_t)((n + 3) & ~3) + 2 * (size_t)((m + 3) & ~3));
   }
   b->lds_per_wave = lds_need(S, b->NL, 1, sc->k1, sc->k2, 1, 1) - lds_need(S, b->NL, 0, sc->k1, sc->k2, 1, 1);
   if (b->lds_bytes > 160 * 1024)

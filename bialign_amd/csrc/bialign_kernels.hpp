@@ -680,6 +680,35 @@ __device__ __forceinline__ int shift_of(int hU, int hV) {
 // the source state added as a one-step look-ahead) is a wave-min over the packed
 // key (|d0|+|d1|, |d1|, c).
 // ---------------------------------------------------------------------------
+// Score tables and the pair's sequence codes staged in LDS for the tracebacks (every
+// column needs mu1, mu2: two dependent global loads otherwise).
+struct TraceInputs {
+  const int32_t *s1, *s2;
+  const uint8_t *sa, *ca, *sb, *cb;
+};
+__device__ __forceinline__ TraceInputs stage_trace_inputs(const DeviceBatch& A, const PairDesc& pd,
+                                                          int32_t* smem) {
+  const int k1 = A.k1, k2 = A.k2, n = pd.n, m = pd.m;
+  int32_t* s1 = smem;
+  int32_t* s2 = s1 + k1 * k1;
+  uint8_t* sa = reinterpret_cast<uint8_t*>(s2 + k2 * k2);
+  uint8_t* ca = sa + ((n + 3) & ~3);
+  uint8_t* sb = ca + ((n + 3) & ~3);
+  uint8_t* cb = sb + ((m + 3) & ~3);
+  for (int t = threadIdx.x; t < k1 * k1; t += 64) s1[t] = A.s1[t];
+  for (int t = threadIdx.x; t < k2 * k2; t += 64) s2[t] = A.s2[t];
+  for (int t = threadIdx.x; t < n; t += 64) {
+    sa[t] = A.seq_a[pd.seq_a + t];
+    ca[t] = A.cls_a[pd.seq_a + t];
+  }
+  for (int t = threadIdx.x; t < m; t += 64) {
+    sb[t] = A.seq_b[pd.seq_b + t];
+    cb[t] = A.cls_b[pd.seq_b + t];
+  }
+  __syncthreads();
+  return TraceInputs{s1, s2, sa, ca, sb, cb};
+}
+
 __device__ __forceinline__ int wave_min16(int v) {  // min over lanes 0..15, valid in every lane < 16
 #pragma unroll
   for (int d = 1; d < 16; d <<= 1) v = min(v, __shfl_xor(v, d, 16));
@@ -693,12 +722,9 @@ __global__ void __launch_bounds__(64) traceback_affine_kernel(const DeviceBatch 
   const int n = pd.n, m = pd.m;
   const int beta = A.beta, gamma = A.gamma, delta = A.delta;
   const int32_t* lay = A.layers;
-  const uint8_t* sa = A.seq_a + pd.seq_a;
-  const uint8_t* ca = A.cls_a + pd.seq_a;
-  const uint8_t* sb = A.seq_b + pd.seq_b;
-  const uint8_t* cb = A.cls_b + pd.seq_b;
   const int c = threadIdx.x;  // candidate lane
   constexpr int BIG = 0x7fffffff;
+  extern __shared__ __align__(16) int32_t smem[];
 
   // pyx:573-582: best end layer, first one with the least shift
   const int endv = c < 9 ? lay[cell_dword<S, 9>(pd, n, m, S, S, c)] : -BIG;
@@ -707,6 +733,8 @@ __global__ void __launch_bounds__(64) traceback_affine_kernel(const DeviceBatch 
   if (!DO_TRACE) return;
   const int skey = (c < 9 && endv == best) ? (shift_of(c / 3, c % 3) << 4 | c) : BIG;
   int st = __builtin_amdgcn_readfirstlane(wave_min16(skey)) & 15;
+  const TraceInputs in = stage_trace_inputs(A, pd, smem);
+  const uint8_t *sa = in.sa, *ca = in.ca, *sb = in.sb, *cb = in.cb;
 
   uint8_t* out = A.trace + pd.trace_off;
   int i = n, j = m, k = n, l = m, d0 = 0, d1 = 0, len = 0, complete = 0;
@@ -718,8 +746,8 @@ __global__ void __launch_bounds__(64) traceback_affine_kernel(const DeviceBatch 
     if (i == 0 && j == 0 && k == 0 && l == 0 && st == 8) { complete = 1; break; }
     const int hU = st / 3, hV = st - 3 * hU;
     const int u0 = hU >= 1, u1 = hU != 1, v0 = hV >= 1, v1 = hV != 1;
-    const int mu1 = (i >= 1 && j >= 1) ? A.s1[sa[i - 1] * A.k1 + sb[j - 1]] : 0;
-    const int mu2 = (k >= 1 && l >= 1) ? A.s2[ca[k - 1] * A.k2 + cb[l - 1]] : 0;
+    const int mu1 = (i >= 1 && j >= 1) ? in.s1[sa[i - 1] * A.k1 + sb[j - 1]] : 0;
+    const int mu2 = (k >= 1 && l >= 1) ? in.s2[ca[k - 1] * A.k2 + cb[l - 1]] : 0;
     const int valU = hU == 2 ? mu1 : gamma, valV = hV == 2 ? mu2 : gamma;
 
     // this lane's candidate: offset, source state, score (pyx:84-131)
@@ -942,15 +970,14 @@ __global__ void __launch_bounds__(64) traceback_linear_kernel(const DeviceBatch 
   const int n = pd.n, m = pd.m;
   const int gamma = A.gamma, delta = A.delta;
   const int32_t* lay = A.layers;
-  const uint8_t* sa = A.seq_a + pd.seq_a;
-  const uint8_t* ca = A.cls_a + pd.seq_a;
-  const uint8_t* sb = A.seq_b + pd.seq_b;
-  const uint8_t* cb = A.cls_b + pd.seq_b;
   const int c = threadIdx.x;
   constexpr int BIG = 0x7fffffff;
+  extern __shared__ __align__(16) int32_t smem[];
   int cur = lay[cell_dword<S, 1>(pd, n, m, S, S, 0)];
   if (c == 0) A.scores[pid] = cur;  // pyx:471
   if (!DO_TRACE) return;
+  const TraceInputs in = stage_trace_inputs(A, pd, smem);
+  const uint8_t *sa = in.sa, *ca = in.ca, *sb = in.sb, *cb = in.cb;
 
   // offsets of the thirteen cases as bit masks o0*8+o1*4+o2*2+o3 (pyx:233-248), per lane
   constexpr int OFF[16] = {15, 10, 5, 12, 3, 8, 4, 2, 1, 11, 7, 14, 13, 0, 0, 0};
@@ -967,8 +994,8 @@ __global__ void __launch_bounds__(64) traceback_linear_kernel(const DeviceBatch 
   uint8_t* out = A.trace + pd.trace_off;
   int i = n, j = m, k = n, l = m, len = 0;
   while (true) {
-    const int mu1 = (i >= 1 && j >= 1) ? A.s1[sa[i - 1] * A.k1 + sb[j - 1]] : 0;
-    const int mu2 = (k >= 1 && l >= 1) ? A.s2[ca[k - 1] * A.k2 + cb[l - 1]] : 0;
+    const int mu1 = (i >= 1 && j >= 1) ? in.s1[sa[i - 1] * A.k1 + sb[j - 1]] : 0;
+    const int mu2 = (k >= 1 && l >= 1) ? in.s2[ca[k - 1] * A.k2 + cb[l - 1]] : 0;
     const int sc = kconst + (use1 ? mu1 : 0) + (use2 ? mu2 : 0);
     const int pi = i - o0, pj = j - o1, pk = k - o2, pl = l - o3;
     const bool ok = c < 13 && pi >= 0 && pj >= 0 && pk >= 0 && pl >= 0 && abs(pk - pi) <= S && abs(pl - pj) <= S;

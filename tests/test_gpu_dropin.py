@@ -262,3 +262,8 @@ def test_full_config5_one_gpu_share():
     layers in two chunks; rank r of 8 would use seeds 1000 + r*1024 + p."""
     info, scores = _full_config_check(synth.protein_batch(1024, 1024), dict(synth.PROTEIN_PARAMS), 16, 1)
     assert info["cells"] == 1024 * 3073 * 3073
+
+
+def test_long_molecules_large_lds():
+    """30 000 x 2 000 at max_shift 0: sequence staging above the default 64 KB of dynamic LDS."""
+    _property_check([synth.protein_pair(91, 30000, 2000)], dict(synth.PROTEIN_PARAMS, max_shift=0))
