@@ -496,7 +496,7 @@ int bialign_batch_create(bialign_engine* eng, const bialign_params* prm, const b
     d.seq_b = pr->off_b[p];
     d.trace_off = b->trace_bytes;
     b->trace_bytes += d.trace_cap;
-    pair_dwords[p] = (int64_t)d.G * 64 * b->NL * W;
+    pair_dwords[p] = (int64_t)d.G * ((64 / W - 1) * W) * b->NL * W;  // Rec<S,NL>::RECDW per step
     b->cells += cells_of(n, m, S);
     tot_a = std::max<int64_t>(tot_a, pr->off_a[p] + n);
     tot_b = std::max<int64_t>(tot_b, pr->off_b[p] + m);

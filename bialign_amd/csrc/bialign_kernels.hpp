@@ -87,19 +87,23 @@ struct Geo {
   static constexpr int PADB = S + 1;     // guard bytes around B codes in LDS
 };
 
-// Record geometry: one record per step, ND dwords per lane, stored as NCH4
-// 16-byte chunks [chunk][lane][4] followed by a [lane][TAIL] tail, so that every
-// store instruction of the wave writes one contiguous 1 KiB (or 256/768 B) run.
+// Record geometry: one record per step, ND dwords for each of the SL = RR*W real lanes
+// (ghost and idle lanes own no storage), as NCH4 chunks [chunk][slot][4 dwords] followed by a
+// [slot][TAIL] tail, everything packed: a wave-wide store instruction writes one contiguous
+// run of SL*16 bytes and consecutive instructions / steps continue where the last one ended,
+// so every byte of a pair's region is written and L2 assembles full lines.
 template <int S, int NL>
 struct Rec {
   static constexpr int W = 2 * S + 1;
+  static constexpr int SL = (64 / W - 1) * W;  // storage slots = real lanes
   static constexpr int ND = NL * W;
   static constexpr int NCH4 = ND / 4;
   static constexpr int TAIL = ND % 4;
-  static constexpr int RECDW = 64 * ND;
-  __host__ __device__ static inline int64_t dword(int64_t g, int lane, int d) {
-    return d < 4 * NCH4 ? g * RECDW + (d >> 2) * 256 + lane * 4 + (d & 3)
-                        : g * RECDW + NCH4 * 256 + lane * TAIL + (d - 4 * NCH4);
+  static constexpr int CH = SL * 4;            // dwords per chunk
+  static constexpr int RECDW = SL * ND;
+  __host__ __device__ static inline int64_t dword(int64_t g, int slot, int d) {
+    return d < 4 * NCH4 ? g * RECDW + (d >> 2) * CH + slot * 4 + (d & 3)
+                        : g * RECDW + NCH4 * CH + slot * TAIL + (d - 4 * NCH4);
   }
 };
 
@@ -110,7 +114,7 @@ __host__ __device__ inline int64_t cell_dword(const PairDesc& pd, int i, int j, 
   constexpr int W = 2 * S + 1, RR = Geo<S>::RR;
   const int strip = i / RR, il = i - strip * RR + 1;
   const int64_t g = (int64_t)strip * pd.P + j + 2 * il + aa;
-  return pd.layer_off + Rec<S, NL>::dword(g, il * W + aa, bb * NL + st);
+  return pd.layer_off + Rec<S, NL>::dword(g, (il - 1) * W + aa, bb * NL + st);
 }
 
 
@@ -160,9 +164,9 @@ struct GhostFeed {
       const int xr = blk_rem + t - aa;
       const int ql = blk_q + (xr >= P ? 1 : 0) - (xr < 0 ? 1 : 0);
       const int rec = min(max(h0 + t - GOFF + (ql * (T - 1) + w) * P, 0), rec_last);
-      const int sl = (R - 1) * W + aa;
+      const int sl = (R - 2) * W + aa;  // storage slot of the bottom real row
       const int32_t* p = lay + (int64_t)rec * R_::RECDW +
-                         (c < R_::NCH4 ? c * 256 + sl * 4 : R_::NCH4 * 256 + sl * R_::TAIL);
+                         (c < R_::NCH4 ? c * R_::CH + sl * 4 : R_::NCH4 * R_::CH + sl * R_::TAIL);
       const uint32_t dst = lds_base + r * 1024;  // wave-uniform; lane l lands at dst + 16*l
       uint32_t keep;
       // sc1: served by L2, never by this CU's L1 (the records may come from the partner wave)
@@ -444,16 +448,17 @@ __global__ void __launch_bounds__(64 * TW) fill_affine_kernel(const DeviceBatch 
     const bool is_origin = INTERIOR ? false : (tile_act && i == 0 && jj == 0 && aa == S);
     const int c3M = mu1 + dd, c_Mg = mu1 + gD;
 
-    // Layer stores (pyx:504: M[state][idx] = ...).  Every lane owns a 16-byte slot in each
-    // chunk of its record, read back only for lattice points that exist; ghost lanes, the
-    // idle lane and out-of-lattice rows store don't-care values there so that the wave
-    // always writes whole 1 KiB runs (full 128-byte lines; masked or half-written lines
-    // cost an HBM read-modify-write).  Only fully idle steps skip the store.  Each chunk is
-    // issued as soon as its four values exist, spreading the stores over the step.
+    // Layer stores (pyx:504: M[state][idx] = ...).  Every real lane owns a 16-byte slot in
+    // each chunk of its record, read back only for lattice points that exist; out-of-lattice
+    // rows store don't-care values there so that no byte of a record stays unwritten (a
+    // line left partly unwritten costs an HBM read-modify-write).  Only fully idle steps skip
+    // the store.  Each chunk is issued as soon as its four values exist, spreading the
+    // stores over the step.
     const int rec = g + rec_base;  // lanes of two strips (straddling steps) hit two records
-    const bool do_store = BIALIGN_EXP != 1 &&
+    const bool do_store = BIALIGN_EXP != 1 && live && !ghost &&
                           (INTERIOR || __builtin_amdgcn_ballot_w64(tile_act && !ghost) != 0) &&
                           ((!XCU && TW == 1) || rec <= rec_last);
+    const int slot = L - W;  // storage slot of a real lane
     int32_t* const dst = BIALIGN_EXP == 2
                              ? A.layers + ((int64_t)(blockIdx.x & 255) << 18) + (int64_t)(g & 31) * RECDW
                              : lay + (int64_t)rec * RECDW;
@@ -543,17 +548,17 @@ __global__ void __launch_bounds__(64 * TW) fill_affine_kernel(const DeviceBatch 
           if (4 * c + 3 >= bb * 9 && 4 * c + 3 < (bb + 1) * 9) {  // chunk c completes with this point
             v4i v;
             v.x = outv[4 * c]; v.y = outv[4 * c + 1]; v.z = outv[4 * c + 2]; v.w = outv[4 * c + 3];
-            store_chunk<XCU>(dst + c * 256 + L * 4, v);
+            store_chunk<XCU>(dst + c * R_::CH + slot * 4, v);
           }
         }
         if (bb == W - 1) {
 #pragma unroll
           for (int t = 0; t < TAIL; ++t) {
             if (XCU)
-              __hip_atomic_store(dst + NCH4 * 256 + L * TAIL + t, outv[4 * NCH4 + t], __ATOMIC_RELAXED,
+              __hip_atomic_store(dst + NCH4 * R_::CH + slot * TAIL + t, outv[4 * NCH4 + t], __ATOMIC_RELAXED,
                                  __HIP_MEMORY_SCOPE_AGENT);
             else
-              dst[NCH4 * 256 + L * TAIL + t] = outv[4 * NCH4 + t];
+              dst[NCH4 * R_::CH + slot * TAIL + t] = outv[4 * NCH4 + t];
           }
         }
       }
@@ -940,16 +945,17 @@ __global__ void __launch_bounds__(64) fill_linear_kernel(const DeviceBatch A) {
       l11[bb] = inL1[bb];
     }
 
-    if (__builtin_amdgcn_ballot_w64(tile_act && !ghost) != 0) {  // whole-wave stores, see the affine kernel
+    if (__builtin_amdgcn_ballot_w64(tile_act && !ghost) != 0 && live && !ghost) {  // see the affine kernel
+      const int slot = L - W;
       int32_t* dst = lay + (int64_t)g * RECDW;
 #pragma unroll
       for (int c = 0; c < NCH4; ++c) {
         v4i v;
         v.x = outv[4 * c]; v.y = outv[4 * c + 1]; v.z = outv[4 * c + 2]; v.w = outv[4 * c + 3];
-        *reinterpret_cast<v4i*>(dst + c * 256 + L * 4) = v;
+        *reinterpret_cast<v4i*>(dst + c * R_::CH + slot * 4) = v;
       }
 #pragma unroll
-      for (int t = 0; t < TAIL; ++t) dst[NCH4 * 256 + L * TAIL + t] = outv[4 * NCH4 + t];
+      for (int t = 0; t < TAIL; ++t) dst[NCH4 * R_::CH + slot * TAIL + t] = outv[4 * NCH4 + t];
     }
     ++jj;
     if (jj == P) {
