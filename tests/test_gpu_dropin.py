@@ -267,3 +267,16 @@ def test_full_config5_one_gpu_share():
 def test_long_molecules_large_lds():
     """30 000 x 2 000 at max_shift 0: sequence staging above the default 64 KB of dynamic LDS."""
     _property_check([synth.protein_pair(91, 30000, 2000)], dict(synth.PROTEIN_PARAMS, max_shift=0))
+
+
+def test_cli_config3_from_files_readme_command(capsys):
+    """The README's own command line (reference README.md:159-161, with the `--filein` abbreviation)
+    on the two example CFSSP files: stdout identical to the reference's."""
+    from bialign_amd import cli
+    with open(os.path.join(GOLDEN, "dnapol_cli_stdout.txt")) as fh:
+        want = fh.read()
+    cli.main(["--filein", os.path.join(GOLDEN, "DNAPolymerase1_Escherichia.cfssp"),
+              os.path.join(GOLDEN, "DNAPolymerase1_Xanthomonas.cfssp"), "--type", "Protein", "--shift_cost", "-150",
+              "--structure_weight", "800", "--simmatrix", "BLOSUM62", "--gap_opening_cost", "-150",
+              "--gap_cost", "-50", "--max_shift", "1"])
+    assert capsys.readouterr().out == want

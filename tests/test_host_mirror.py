@@ -164,3 +164,22 @@ def test_batch_cli_input(tmp_path):
         batch_cli.read_pairs(str(tmp_path / "bad.tsv"))
     ns = batch_cli.build_parser().parse_args([str(f), "--type", "Protein", "--max_shift", "1", "--outmode", "raw"])
     assert ns.type == "Protein" and ns.max_shift == 1 and ns.gap_cost == -200 and not hasattr(ns, "seqA")
+
+
+def test_cfssp_example_files_parse_to_config3_inputs():
+    """The reference's two example inputs (BASELINE config 3; data files copied as fixtures) parse to
+    exactly the sequences / structures the reference CLI echoed."""
+    import os
+    from conftest import GOLDEN
+    with open(os.path.join(GOLDEN, "dnapol_cli_stdout.txt")) as fh:
+        lines = fh.read().split("\n")
+    want = [lines[t].split("\t ")[1] for t in (1, 2, 3, 4)]
+    a = ba.read_molecule_from_file(os.path.join(GOLDEN, "DNAPolymerase1_Escherichia.cfssp"), "Protein")
+    b = ba.read_molecule_from_file(os.path.join(GOLDEN, "DNAPolymerase1_Xanthomonas.cfssp"), "Protein")
+    assert [a[0], b[0], a[1], b[1]] == want and (len(a[0]), len(b[0])) == (928, 933)
+
+
+def test_missing_input_file_exits_like_the_intended_reference(capsys):
+    with pytest.raises(SystemExit):
+        ba.read_molecule_from_file("/nonexistent/file.cfssp", "Protein")
+    assert "Input file not found." in capsys.readouterr().out
