@@ -145,7 +145,9 @@ def main():
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "int32", "data": "synthetic",
             "pairs_per_s": total_pairs * args.steps / elapsed,
-            "config": {"workload": f"{args.pairs} synthetic protein pairs per GPU, len {args.length}, "
+            "config": {"baseline_config": "BASELINE.json configs[1] per GPU" if (args.pairs, args.length, args.max_shift) == (1024, 512, 1)
+                                          else "custom (--pairs/--len/--max_shift)",
+                       "workload": f"{args.pairs} synthetic protein pairs per GPU, len {args.length}, "
                                    f"BLOSUM62, affine gaps (beta=-150, gamma=-50, Delta=-150, sw=800), "
                                    f"max_shift={args.max_shift}; fill + traceback + score gather",
                        "pairs_per_gpu": args.pairs, "len": args.length, "max_shift": args.max_shift,
