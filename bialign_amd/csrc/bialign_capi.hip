@@ -148,7 +148,7 @@ size_t lds_need(int S, int NL, int team, int k1, int k2, int n, int m) {
   const size_t npad = (n + 3) & ~3, mpad = (m + 2 * PADB + 3) & ~3;
   const int nd = NL * W, np = nd / 4 + (nd % 4 ? 1 : 0), blk = ghost_blk(S);
   const size_t ring_dw = 2 * (((size_t)blk * W * np + 63) / 64 * 64) * 4;  // GhostFeed<S,NL>::RING_DW
-  const size_t shared_dw = (NL == 9 ? 16 : 0) + (size_t)k1 * k1 + (size_t)k2 * k2;
+  const size_t shared_dw = 16 + (size_t)k1 * k1 + (size_t)k2 * k2;  // progress words + score tables
   return (team * (ring_dw + nv * NCOL) + shared_dw) * 4 + 2 * npad + 2 * mpad;
 }
 
@@ -190,7 +190,6 @@ int launch_fill_affine_t(bialign_batch* b, const DeviceBatch& v, int first, int 
 //    predecessor), so the grid is capped by the LDS-limited residency of the device.
 TeamShape team_shape(const bialign_batch* b, int first, int count) {
   TeamShape ts;
-  if (!b->affine) return ts;
   const int W = 2 * b->S + 1, R = 64 / W;
   const int lag = 2 * (R - 1) + 2 * ghost_blk(b->S) + 16;
   int fit = 32;  // largest team the pairs of this launch allow
@@ -198,14 +197,15 @@ TeamShape team_shape(const bialign_batch* b, int first, int count) {
     const PairDesc& d = b->pairs[b->order[t]];
     while (fit > 1 && (d.P < std::max(256, fit * lag + 64) || d.NS < 2 * fit)) fit >>= 1;
   }
-  int tw = std::min(fit, b->S <= 1 ? 8 : (b->S <= 3 ? 4 : 1));
+  // the one-layer (non-affine) kernel is small in registers at every s
+  int tw = std::min(fit, !b->affine ? 8 : (b->S <= 1 ? 8 : (b->S <= 3 ? 4 : 1)));
   while (tw > 1 && b->lds_base + (size_t)tw * b->lds_per_wave > 160 * 1024) tw >>= 1;
   // one-wave workgroups resident per CU (LDS-limited; allocation granularity 1 KiB)
   const size_t lds1 = (b->lds_base + b->lds_per_wave + 1023) / 1024 * 1024;
   // ... and register-limited: the s<=2 kernels allow >= 2 waves per SIMD, s=3 one wave per SIMD
   const size_t by_regs = b->S <= 2 ? 8 : 4;
   const int resident = b->eng->num_cu * (int)std::min<size_t>(by_regs, (160 * 1024) / lds1);
-  int gw = b->S <= 3 ? fit : 1;
+  int gw = (b->affine && b->S <= 3) ? fit : 1;  // cross-CU teams: affine kernels only
   while (gw > 1 && (int64_t)count * gw > resident) gw >>= 1;
 
   const char* e = getenv("BIALIGN_TEAM");  // experiments / tests: "N" in-workgroup, "xN" cross-CU
@@ -223,7 +223,7 @@ TeamShape team_shape(const bialign_batch* b, int first, int count) {
   }
   // in-workgroup: the smallest team that (nearly) maximises the waves running at once, given
   // how many workgroups of that size a CU holds (LDS, registers)
-  const int waves_cu_regs = b->S <= 1 ? 12 : (b->S == 2 ? 8 : 4);
+  const int waves_cu_regs = !b->affine ? 16 : (b->S <= 1 ? 12 : (b->S == 2 ? 8 : 4));
   auto concurrent = [&](int t) {
     const size_t lds = (b->lds_base + (size_t)t * b->lds_per_wave + 1023) / 1024 * 1024;
     const int wg_cu = (int)std::min<size_t>((160 * 1024) / lds, (size_t)(waves_cu_regs / t));
@@ -279,17 +279,30 @@ int launch_traceback_affine(const bialign_batch* b, const DeviceBatch& v, int fi
   return BIALIGN_OK;
 }
 
-template <int S>
-int launch_fill_linear(bialign_batch* b, const DeviceBatch& v, int first, int count) {
+template <int S, int TW>
+int launch_fill_linear_t(bialign_batch* b, const DeviceBatch& v, int first, int count) {
   DeviceBatch w = v;
   w.order = v.order + first;
-  auto kern = fill_linear_kernel<S>;
-  if (b->lds_bytes > 64 * 1024)
+  auto kern = fill_linear_kernel<S, TW>;
+  const size_t lds = b->lds_base + (size_t)TW * b->lds_per_wave;
+  if (lds > 64 * 1024)
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_bytes));
-  hipLaunchKernelGGL(kern, dim3(count), dim3(64), b->lds_bytes, b->eng->stream, w);
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(kern, dim3(count), dim3(64 * TW), lds, b->eng->stream, w);
   HIP_TRY(hipGetLastError());
   return BIALIGN_OK;
+}
+
+template <int S>
+int launch_fill_linear(bialign_batch* b, const DeviceBatch& v, int first, int count) {
+  const TeamShape ts = team_shape(b, first, count);
+  b->last_team = ts.tw;
+  switch (ts.tw) {
+    case 8: return launch_fill_linear_t<S, 8>(b, v, first, count);
+    case 4: return launch_fill_linear_t<S, 4>(b, v, first, count);
+    case 2: return launch_fill_linear_t<S, 2>(b, v, first, count);
+    default: return launch_fill_linear_t<S, 1>(b, v, first, count);
+  }
 }
 
 template <int S>

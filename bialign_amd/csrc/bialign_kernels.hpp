@@ -806,17 +806,19 @@ __global__ void __launch_bounds__(64) traceback_affine_kernel(const DeviceBatch 
 // later and kept in registers for the cases that need them 2 or 3 steps later
 // (age of offset o = o0 + o1 + o2).
 // ---------------------------------------------------------------------------
-template <int S>
-__global__ void __launch_bounds__(64) fill_linear_kernel(const DeviceBatch A) {
+template <int S, int TW>
+__global__ void __launch_bounds__(64 * TW) fill_linear_kernel(const DeviceBatch A) {
   using G_ = Geo<S>;
   using R_ = Rec<S, 1>;
   constexpr int W = G_::W, R = G_::R, RR = G_::RR, PADB = G_::PADB;
   constexpr int NV = W, ND = R_::ND, NCH4 = R_::NCH4, TAIL = R_::TAIL, RECDW = R_::RECDW;
   extern __shared__ __align__(16) int32_t smem[];
 
+  constexpr int T = TW;  // team = the workgroup's waves (see fill_affine_kernel)
   const PairDesc pd = A.pairs[A.order[blockIdx.x]];
   const int n = pd.n, m = pd.m, P = pd.P;
-  const int L = threadIdx.x;
+  const int L = threadIdx.x & 63;
+  const int w = TW == 1 ? 0 : __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int il = L / W, aa = L - il * W;
   const bool live = L < R * W;
   const bool ghost = (il == 0);
@@ -825,9 +827,10 @@ __global__ void __launch_bounds__(64) fill_linear_kernel(const DeviceBatch A) {
   const int gD = gamma + delta, gg = 2 * gamma;
 
   using GF = GhostFeed<S, 1>;
-  v4i* ring = reinterpret_cast<v4i*>(smem);
-  int32_t* xch = smem + GF::RING_DW;
-  int32_t* s1 = xch + NV * NCOL;
+  v4i* ring = reinterpret_cast<v4i*>(smem + w * GF::RING_DW);
+  int32_t* xch = smem + TW * GF::RING_DW + w * (NV * NCOL);
+  volatile int32_t* prog = smem + TW * (GF::RING_DW + NV * NCOL);  // [16] steps with acknowledged stores
+  int32_t* s1 = smem + TW * (GF::RING_DW + NV * NCOL) + 16;
   int32_t* s2 = s1 + k1 * k1;
   const int npad = (n + 3) & ~3, mpad = (m + 2 * PADB + 3) & ~3;
   uint8_t* sa = reinterpret_cast<uint8_t*>(s2 + k2 * k2);
@@ -835,15 +838,15 @@ __global__ void __launch_bounds__(64) fill_linear_kernel(const DeviceBatch A) {
   uint8_t* sb = ca + npad;
   uint8_t* cb = sb + mpad;
 
-  for (int t = L; t < GF::RING_DW; t += 64) smem[t] = SENT;
-  for (int t = L; t < NV * NCOL; t += 64) xch[t] = SENT;
-  for (int t = L; t < k1 * k1; t += 64) s1[t] = A.s1[t];
-  for (int t = L; t < k2 * k2; t += 64) s2[t] = A.s2[t];
-  for (int t = L; t < n; t += 64) {
+  for (int t = threadIdx.x; t < TW * (GF::RING_DW + NV * NCOL); t += 64 * TW) smem[t] = SENT;
+  if (threadIdx.x < 16) prog[threadIdx.x] = 0;
+  for (int t = threadIdx.x; t < k1 * k1; t += 64 * TW) s1[t] = A.s1[t];
+  for (int t = threadIdx.x; t < k2 * k2; t += 64 * TW) s2[t] = A.s2[t];
+  for (int t = threadIdx.x; t < n; t += 64 * TW) {
     sa[t] = A.seq_a[pd.seq_a + t];
     ca[t] = A.cls_a[pd.seq_a + t];
   }
-  for (int t = L; t < m + 2 * PADB; t += 64) {
+  for (int t = threadIdx.x; t < m + 2 * PADB; t += 64 * TW) {
     const int src = t - PADB;
     const bool ok = src >= 0 && src < m;
     sb[t] = ok ? A.seq_b[pd.seq_b + src] : 0;
@@ -857,12 +860,16 @@ __global__ void __launch_bounds__(64) fill_linear_kernel(const DeviceBatch A) {
   const int GOFF = P - 2 * (R - 1);
   int32_t* const lay = A.layers + pd.layer_off;
 
+  const int rec_last = pd.G - 1;
+  const int NSw = (pd.NS - w + T - 1) / T;  // this wave's strips: w, w+T, ...
+  const int H = NSw > 0 ? (NSw - 1) * P + m + G_::MAXOFF + 1 : 0;
   int jj = -(2 * il + aa);
-  int strip = 0;
+  int strip = 0;         // local strip index q; lattice strip = q*T + w
+  int rec_base = w * P;  // record of local step h for this lane = h + rec_base
   int i = 0, s1row = 0, s2row = 0;
   bool act_row = false;
-  auto set_row = [&](int st) {
-    i = st * RR + il - 1;
+  auto set_row = [&](int q) {
+    i = (q * T + w) * RR + il - 1;
     const int k = i + aa - S;
     act_row = live && i >= 0 && i <= n && k >= 0 && k <= n;
     s1row = (i >= 1 && i <= n) ? sa[i - 1] * k1 : 0;
@@ -878,14 +885,39 @@ __global__ void __launch_bounds__(64) fill_linear_kernel(const DeviceBatch A) {
 #pragma unroll
   for (int bb = 0; bb < W; ++bb) lw1[bb] = lw2[bb] = lwp1[bb] = l11[bb] = selfM[bb] = ghostM[bb] = SENT;
   const uint32_t ring_lds = __builtin_amdgcn_readfirstlane(
-      (uint32_t)(uintptr_t)(__attribute__((address_space(3))) int32_t*)smem);
+      (uint32_t)(uintptr_t)(__attribute__((address_space(3))) int32_t*)smem) + w * GF::RING_DW * 4;
 
-  for (int g = 0; g < pd.G; ++g) {
+  // team protocol, as in fill_affine_kernel (in-workgroup form)
+  int blk_q = 0, blk_rem = 0;
+  bool team_failed = false;
+  auto wait_partner = [&](int h_last) __attribute__((always_inline)) {
+    if (T == 1 || team_failed) return;
+    const int src = w == 0 ? T - 1 : w - 1;
+    const int need = h_last + 2 * (R - 1) + 1 - (w == 0 ? P : 0);
+    for (int spin = 0; prog[src] < need; ++spin) {
+      if (spin > (1 << 20)) {
+        if (L == 0) atomicExch(A.errflag, 1);
+        team_failed = true;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(16);
+    }
+  };
+  auto prefetch_block = [&](int h0, int half) __attribute__((always_inline)) {
+    wait_partner(h0 + GF::BLK - 1);
+    GF::issue(lay, h0, blk_q, blk_rem, P, T, w, GOFF, rec_last, L, ring_lds + half * GF::SLOTS * 16);
+    blk_rem += GF::BLK;
+    if (blk_rem >= P) { blk_rem -= P; ++blk_q; }
+  };
+  prefetch_block(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+  for (int g = 0; g < H; ++g) {
     const int gt = g & (GF::BLK - 1), ghalf = (g / GF::BLK) & 1;
     if (gt == 0) {
       GF::wait_block();
-      GF::issue(lay, (g / GF::BLK + 1) * GF::BLK, 0, 0, P, 1, 0, GOFF, pd.G - 1, L,
-                            ring_lds + (ghalf ^ 1) * GF::SLOTS * 16);
+      if (T > 1 && L == 0) prog[w] = g - 8;
+      prefetch_block(g + GF::BLK, ghalf ^ 1);
     }
     GF::fetch(ghostM, ring + ghalf * GF::SLOTS, gt, aa);
     int inLW[W], inLW1[W], inL1[W];
@@ -945,9 +977,11 @@ __global__ void __launch_bounds__(64) fill_linear_kernel(const DeviceBatch A) {
       l11[bb] = inL1[bb];
     }
 
-    if (__builtin_amdgcn_ballot_w64(tile_act && !ghost) != 0 && live && !ghost) {  // see the affine kernel
+    const int rec = g + rec_base;
+    if (__builtin_amdgcn_ballot_w64(tile_act && !ghost) != 0 && live && !ghost &&
+        (T == 1 || rec <= rec_last)) {  // see the affine kernel
       const int slot = L - W;
-      int32_t* dst = lay + (int64_t)g * RECDW;
+      int32_t* dst = lay + (int64_t)rec * RECDW;
 #pragma unroll
       for (int c = 0; c < NCH4; ++c) {
         v4i v;
@@ -961,8 +995,13 @@ __global__ void __launch_bounds__(64) fill_linear_kernel(const DeviceBatch A) {
     if (jj == P) {
       jj = 0;
       ++strip;
+      rec_base += (T - 1) * P;
       set_row(strip);
     }
+  }
+  if (T > 1) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (L == 0) prog[w] = 0x7fffffff;
   }
 }
 

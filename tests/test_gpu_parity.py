@@ -194,3 +194,20 @@ def test_dump_layers_of_any_pair_in_a_batch():
         for g, e in zip(oracle.band_values(b.dump_layers(t), n, m, 1), oracle.band_values(ref["layers"], n, m, 1)):
             np.testing.assert_array_equal(g, e)
     b.close()
+
+
+@pytest.mark.parametrize("n,m,s,seed,team", [(300, 320, 1, 41, 2), (330, 650, 1, 42, 8), (200, 400, 2, 43, 4),
+                                              (420, 400, 0, 44, 2), (150, 300, 3, 45, 2)])
+def test_team_sweep_linear_full_layers(n, m, s, seed, team, monkeypatch):
+    """The non-affine (13-case) fill with T waves per pair: the layer, trace and score."""
+    from oracle import oracle
+    monkeypatch.setenv("BIALIGN_TEAM", str(team))
+    sa, sb, ta, tb = synth.protein_pair(seed, n, m)
+    params = dict(synth.PROTEIN_PARAMS, max_shift=s, gap_opening_cost=0, gap_cost=-200, shift_cost=-250)
+    rec = dict(seqA=sa, seqB=sb, strA=ta, strB=tb, params=params)
+    ref = oracle.solve(sa, sb, ta, tb, params)
+    got = gpu_solve(rec, layers=True)
+    assert got["timing"]["waves_per_pair"] == team
+    assert got["score"] == ref["score"] and got["trace"] == oracle.trace_to_lists(ref["trace"])
+    for g, e in zip(oracle.band_values(got["layers"], n, m, s), oracle.band_values(ref["layers"], n, m, s)):
+        np.testing.assert_array_equal(g, e)
