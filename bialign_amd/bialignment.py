@@ -279,7 +279,6 @@ class BiAligner:
 
     # --------------------------------------------------------------- GPU calls
     def _run_engine(self, recurrence):
-        from . import _lib
         from .engine import Batch, default_engine
         if any(m.get("predicted") for m in (self.molA, self.molB)):
             raise NotImplementedError(

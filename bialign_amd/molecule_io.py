@@ -3,7 +3,6 @@ matrices, CFSSP files, alignment line utilities (reference
 bialignment_nonpyx.py:1-141).  Plotting (nonpyx:144-367) is outside the
 accelerated path and not provided; ``plot_alignment`` says so when called.
 """
-import os
 import sys
 
 from .scoring import load_matrix_table, read_simmatrix  # noqa: F401  (re-exported)

@@ -7,7 +7,6 @@ needed so that ``decode_trace`` output is byte-identical to the reference
 """
 import ctypes
 import os
-from math import sqrt
 
 import numpy as np
 

@@ -1,5 +1,5 @@
 """Throughput of the other BASELINE shapes / kernel variants (not the bench line)."""
-import os, sys, time
+import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bialign_amd import synth
 from bialign_amd.batch import make_batch
