@@ -10,7 +10,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("BIALIGN_LIB_OVERRIDE") or os.path.join(HERE, "libbialign_hip.so")  # override: timing experiments only
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 RUN_FILL_ONLY = 1
 REC_AUTO, REC_AFFINE, REC_LINEAR = 0, 1, 2
 MAX_SHIFT = 5
@@ -35,7 +35,7 @@ class Scoring(ctypes.Structure):
 class Pairs(ctypes.Structure):
     _fields_ = [("npairs", ctypes.c_int32), ("len_a", c_i32p), ("len_b", c_i32p),
                 ("off_a", c_i64p), ("off_b", c_i64p), ("seq_a", c_u8p), ("cls_a", c_u8p),
-                ("seq_b", c_u8p), ("cls_b", c_u8p)]
+                ("seq_b", c_u8p), ("cls_b", c_u8p), ("mu2_dense", c_i32p), ("mu2_off", c_i64p)]
 
 
 class BatchInfo(ctypes.Structure):

@@ -104,6 +104,11 @@ _LINEAR_OFFSETS = ((1, 1, 1, 1), (1, 0, 1, 0), (0, 1, 0, 1), (1, 1, 0, 0), (0, 0
                    (1, 0, 1, 1), (0, 1, 1, 1), (1, 1, 1, 0), (1, 1, 0, 1))  # pyx:233-248
 
 
+def _binary_features(mol):
+    """True when up/down/unp hold only 0.0 / 1.0, i.e. come from a fixed structure string."""
+    return all(v in (0.0, 1.0) for key in ("up", "down", "unp") for v in mol[key][1:])
+
+
 class BiAligner:
     """Bi-alignment of two molecules; DP on the GPU (pyx:155)."""
 
@@ -280,21 +285,26 @@ class BiAligner:
     # --------------------------------------------------------------- GPU calls
     def _run_engine(self, recurrence):
         from .engine import Batch, default_engine
-        if any(m.get("predicted") for m in (self.molA, self.molB)):
-            raise NotImplementedError(
-                "RNA input without explicit structures (ViennaRNA pair probabilities) needs the "
-                "dense-mu2 engine mode, which is not built yet (SURVEY.md section 8f, row 3)")
         A, B = self.molA, self.molB
         model = ScoreModel(self._params, sequences=[A["seq"], B["seq"]],
                            structures=[A["structure"], B["structure"]])
         if self._batch is not None:
             self._batch.close()
         device = int(self._params.get("device", os.environ.get("BIALIGN_DEVICE", 0)) or 0)
+        dense = None
+        if self._is_rna and any(m.get("predicted") or not _binary_features(m) for m in (A, B)):
+            # predicted structures: the features are real numbers, mu2 goes to the engine as a table
+            from .scoring import dense_mu2_from_features
+            dense = [dense_mu2_from_features(A, B, self._params["structure_weight"])]
+            cls_a = np.zeros(A["len"], dtype=np.uint8)
+            cls_b = np.zeros(B["len"], dtype=np.uint8)
+        else:
+            cls_a, cls_b = model.encode_structure(A["structure"]), model.encode_structure(B["structure"])
         self._batch = Batch(default_engine(device),
-                            [(model.encode_sequence(A["seq"]), model.encode_structure(A["structure"]))],
-                            [(model.encode_sequence(B["seq"]), model.encode_structure(B["structure"]))],
+                            [(model.encode_sequence(A["seq"]), cls_a)],
+                            [(model.encode_sequence(B["seq"]), cls_b)],
                             model.s1, model.s2, self.beta, self.gamma, self._params["shift_cost"],
-                            self.max_shift, recurrence=recurrence)
+                            self.max_shift, recurrence=recurrence, mu2_dense=dense)
         self._batch.run()
         self._ran_affine = self._batch.affine
         self._score = np.int64(self._batch.scores()[0])

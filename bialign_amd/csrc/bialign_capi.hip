@@ -118,6 +118,8 @@ struct bialign_batch {
   DevBuf<int32_t> d_order, d_s1, d_s2, d_layers, d_scores, d_tlen, d_complete, d_err, d_prog;
   int last_team = 1;  // waves per pair of the last fill launch (negative: cross-CU team)
   DevBuf<uint8_t> d_seq_a, d_cls_a, d_seq_b, d_cls_b, d_trace;
+  DevBuf<int32_t> d_mu2;  // dense-mu2 mode: all pairs' n x m tables
+  bool dense = false;
   int k1 = 0, k2 = 0;
   bialign_timing timing{};
   bool ran = false, ran_trace = false;
@@ -136,20 +138,22 @@ struct bialign_batch {
     v.trace_len = d_tlen.p;
     v.complete = d_complete.p;
     v.errflag = d_err.p;
+    v.mu2_dense = dense ? d_mu2.p : nullptr;
     return v;
   }
 };
 
 namespace {
 
-size_t lds_need(int S, int NL, int team, int k1, int k2, int n, int m) {
+size_t lds_need(int S, int NL, int team, int k1, int k2, int n, int m, bool dense = false) {
   const int W = 2 * S + 1, PADB = S + 1;
   const size_t nv = (NL == 9 ? 12 : 1) * W;
   const size_t npad = (n + 3) & ~3, mpad = (m + 2 * PADB + 3) & ~3;
   const int nd = NL * W, np = nd / 4 + (nd % 4 ? 1 : 0), blk = ghost_blk(S);
   const size_t ring_dw = 2 * (((size_t)blk * W * np + 63) / 64 * 64) * 4;  // GhostFeed<S,NL>::RING_DW
   const size_t shared_dw = 16 + (size_t)k1 * k1 + (size_t)k2 * k2;  // progress words + score tables
-  return (team * (ring_dw + nv * NCOL) + shared_dw) * 4 + 2 * npad + 2 * mpad;
+  const size_t mu2_ring_dw = dense ? 2 * (size_t)blk * 64 : 0;  // Mu2Feed<S>::RING_DW
+  return (team * (ring_dw + nv * NCOL + mu2_ring_dw) + shared_dw) * 4 + 2 * npad + 2 * mpad;
 }
 
 // One launch shape: TW waves per workgroup, GW workgroups per pair (GW > 1 = cross-CU team).
@@ -158,12 +162,12 @@ struct TeamShape {
   int waves() const { return tw * gw; }
 };
 
-template <int S, bool BETA_NONPOS, int TW, bool XCU>
+template <int S, bool BETA_NONPOS, int TW, bool XCU, bool DENSE = false>
 int launch_fill_affine_t(bialign_batch* b, const DeviceBatch& v, int first, int count, int gw) {
   DeviceBatch w = v;
   w.order = v.order + first;
   w.team = gw;
-  auto kern = fill_affine_kernel<S, BETA_NONPOS, TW, XCU>;
+  auto kern = fill_affine_kernel<S, BETA_NONPOS, TW, XCU, DENSE>;
   const size_t lds = b->lds_base + (size_t)TW * b->lds_per_wave;
   if (lds > 64 * 1024)
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -205,7 +209,8 @@ TeamShape team_shape(const bialign_batch* b, int first, int count) {
   // ... and register-limited: the s<=2 kernels allow >= 2 waves per SIMD, s=3 one wave per SIMD
   const size_t by_regs = b->S <= 2 ? 8 : 4;
   const int resident = b->eng->num_cu * (int)std::min<size_t>(by_regs, (160 * 1024) / lds1);
-  int gw = (b->affine && b->S <= 3) ? fit : 1;  // cross-CU teams: affine kernels only
+  if (b->dense) tw = std::min(tw, 2);  // dense-mu2 kernels are instantiated for 1 and 2 waves
+  int gw = (b->affine && b->S <= 3 && !b->dense) ? fit : 1;  // cross-CU teams: affine LOOKUP kernels only
   while (gw > 1 && (int64_t)count * gw > resident) gw >>= 1;
 
   const char* e = getenv("BIALIGN_TEAM");  // experiments / tests: "N" in-workgroup, "xN" cross-CU
@@ -245,10 +250,20 @@ TeamShape team_shape(const bialign_batch* b, int first, int count) {
 
 template <int S>
 int launch_fill_affine(bialign_batch* b, const DeviceBatch& v, int first, int count) {
-  if (b->prm.gap_opening_cost > 0)  // rare: general-beta algebra, one wave per pair
-    return launch_fill_affine_t<S, false, 1, false>(b, v, first, count, 1);
+  if (b->prm.gap_opening_cost > 0) {  // rare: general-beta algebra, one wave per pair
+    b->last_team = 1;
+    return b->dense ? launch_fill_affine_t<S, false, 1, false, true>(b, v, first, count, 1)
+                    : launch_fill_affine_t<S, false, 1, false>(b, v, first, count, 1);
+  }
   const TeamShape ts = team_shape(b, first, count);
   b->last_team = ts.waves() * (ts.gw > 1 ? -1 : 1);
+  if (b->dense) {
+    if constexpr (S <= 3) {
+      if (ts.tw >= 2) return launch_fill_affine_t<S, true, 2, false, true>(b, v, first, count, 1);
+    }
+    b->last_team = 1;
+    return launch_fill_affine_t<S, true, 1, false, true>(b, v, first, count, 1);
+  }
   if constexpr (S <= 3) {
     if (ts.gw > 1) return launch_fill_affine_t<S, true, 1, true>(b, v, first, count, ts.gw);
   }
@@ -279,11 +294,11 @@ int launch_traceback_affine(const bialign_batch* b, const DeviceBatch& v, int fi
   return BIALIGN_OK;
 }
 
-template <int S, int TW>
+template <int S, int TW, bool DENSE = false>
 int launch_fill_linear_t(bialign_batch* b, const DeviceBatch& v, int first, int count) {
   DeviceBatch w = v;
   w.order = v.order + first;
-  auto kern = fill_linear_kernel<S, TW>;
+  auto kern = fill_linear_kernel<S, TW, DENSE>;
   const size_t lds = b->lds_base + (size_t)TW * b->lds_per_wave;
   if (lds > 64 * 1024)
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -297,6 +312,9 @@ template <int S>
 int launch_fill_linear(bialign_batch* b, const DeviceBatch& v, int first, int count) {
   const TeamShape ts = team_shape(b, first, count);
   b->last_team = ts.tw;
+  if (b->dense)
+    return ts.tw >= 2 ? launch_fill_linear_t<S, 2, true>(b, v, first, count)
+                      : launch_fill_linear_t<S, 1, true>(b, v, first, count);
   switch (ts.tw) {
     case 8: return launch_fill_linear_t<S, 8>(b, v, first, count);
     case 4: return launch_fill_linear_t<S, 4>(b, v, first, count);
@@ -479,6 +497,9 @@ int bialign_batch_create(bialign_engine* eng, const bialign_params* prm, const b
   b->npairs = pr->npairs;
   b->k1 = sc->k1;
   b->k2 = sc->k2;
+  b->dense = pr->mu2_dense != nullptr;
+  if (b->dense && !pr->mu2_off) return fail(BIALIGN_E_INVALID, "mu2_dense given without mu2_off");
+  if (!b->dense && (!pr->cls_a || !pr->cls_b)) return fail(BIALIGN_E_INVALID, "cls_a / cls_b are NULL (LOOKUP form)");
   const int S = b->S, W = 2 * S + 1;
 
   // int32 safety window: finite scores and the drift of "-infinity" cells must
@@ -487,10 +508,18 @@ int bialign_batch_create(bialign_engine* eng, const bialign_params* prm, const b
   for (int t = 0; t < sc->k1 * sc->k1; ++t) amax = std::max<int64_t>(amax, std::llabs((long long)sc->s1[t]));
   int64_t bmax = 0;
   for (int t = 0; t < sc->k2 * sc->k2; ++t) bmax = std::max<int64_t>(bmax, std::llabs((long long)sc->s2[t]));
+  if (b->dense) {  // dense mu2: the bound comes from the tables themselves
+    bmax = 0;
+    for (int p = 0; p < pr->npairs; ++p) {
+      const int64_t cnt = (int64_t)std::max(pr->len_a[p], 0) * std::max(pr->len_b[p], 0);
+      for (int64_t t = 0; t < cnt; ++t)
+        bmax = std::max<int64_t>(bmax, std::llabs((long long)pr->mu2_dense[pr->mu2_off[p] + t]));
+    }
+  }
   const int64_t colmax = amax + bmax + 2 * (std::llabs((long long)prm->gap_cost) + std::llabs((long long)prm->gap_opening_cost)) +
                          2 * std::llabs((long long)prm->shift_cost);
 
-  int64_t tot_a = 0, tot_b = 0;
+  int64_t tot_a = 0, tot_b = 0, tot_mu2 = 0;
   b->pairs.resize(pr->npairs);
   std::vector<int64_t> pair_dwords(pr->npairs);
   for (int p = 0; p < pr->npairs; ++p) {
@@ -508,17 +537,19 @@ int bialign_batch_create(bialign_engine* eng, const bialign_params* prm, const b
     d.seq_a = pr->off_a[p];
     d.seq_b = pr->off_b[p];
     d.trace_off = b->trace_bytes;
+    d.mu2_off = b->dense ? pr->mu2_off[p] : 0;
+    if (b->dense) tot_mu2 = std::max<int64_t>(tot_mu2, pr->mu2_off[p] + (int64_t)n * m);
     b->trace_bytes += d.trace_cap;
     pair_dwords[p] = (int64_t)d.G * ((64 / W - 1) * W) * b->NL * W;  // Rec<S,NL>::RECDW per step
     b->cells += cells_of(n, m, S);
     tot_a = std::max<int64_t>(tot_a, pr->off_a[p] + n);
     tot_b = std::max<int64_t>(tot_b, pr->off_b[p] + m);
-    b->lds_bytes = std::max(b->lds_bytes, lds_need(S, b->NL, 1, sc->k1, sc->k2, n, m));
-    b->lds_base = std::max(b->lds_base, lds_need(S, b->NL, 0, sc->k1, sc->k2, n, m));
+    b->lds_bytes = std::max(b->lds_bytes, lds_need(S, b->NL, 1, sc->k1, sc->k2, n, m, b->dense));
+    b->lds_base = std::max(b->lds_base, lds_need(S, b->NL, 0, sc->k1, sc->k2, n, m, b->dense));
     b->lds_trace = std::max<size_t>(b->lds_trace, ((size_t)sc->k1 * sc->k1 + (size_t)sc->k2 * sc->k2) * 4 +
                                                       2 * (size_t)((n + 3) & ~3) + 2 * (size_t)((m + 3) & ~3));
   }
-  b->lds_per_wave = lds_need(S, b->NL, 1, sc->k1, sc->k2, 1, 1) - lds_need(S, b->NL, 0, sc->k1, sc->k2, 1, 1);
+  b->lds_per_wave = lds_need(S, b->NL, 1, sc->k1, sc->k2, 1, 1, b->dense) - lds_need(S, b->NL, 0, sc->k1, sc->k2, 1, 1, b->dense);
   if (b->lds_bytes > 160 * 1024)
     return fail(BIALIGN_E_UNSUPPORTED, "molecules too long for the LDS staging (%zu bytes needed)", b->lds_bytes);
 
@@ -564,9 +595,12 @@ int bialign_batch_create(bialign_engine* eng, const bialign_params* prm, const b
   HIP_TRY(b->d_s1.upload(sc->s1, (size_t)sc->k1 * sc->k1, st));
   HIP_TRY(b->d_s2.upload(sc->s2, (size_t)sc->k2 * sc->k2, st));
   HIP_TRY(b->d_seq_a.upload(pr->seq_a, tot_a, st));
-  HIP_TRY(b->d_cls_a.upload(pr->cls_a, tot_a, st));
+  std::vector<uint8_t> zeros;
+  if (b->dense) zeros.assign((size_t)std::max(tot_a, tot_b), 0);  // class codes are unused in dense mode
+  HIP_TRY(b->d_cls_a.upload(b->dense ? zeros.data() : pr->cls_a, tot_a, st));
   HIP_TRY(b->d_seq_b.upload(pr->seq_b, tot_b, st));
-  HIP_TRY(b->d_cls_b.upload(pr->cls_b, tot_b, st));
+  HIP_TRY(b->d_cls_b.upload(b->dense ? zeros.data() : pr->cls_b, tot_b, st));
+  if (b->dense) HIP_TRY(b->d_mu2.upload(pr->mu2_dense, (size_t)tot_mu2, st));
   HIP_TRY(b->d_layers.alloc(b->max_chunk_dwords + 16));  // slack: ghost tail pieces are read 16 B wide
   HIP_TRY(b->d_scores.alloc(pr->npairs));
   HIP_TRY(b->d_tlen.alloc(pr->npairs));

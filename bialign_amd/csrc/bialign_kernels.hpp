@@ -58,6 +58,7 @@ struct PairDesc {
   int64_t seq_a, seq_b;   // offsets into the code arrays
   int64_t layer_off;      // dword offset of this pair's records in the chunk buffer
   int64_t trace_off;      // byte offset in the trace buffer
+  int64_t mu2_off;        // dense-mu2 mode: start of this pair's n x m table
 };
 
 struct DeviceBatch {
@@ -73,6 +74,7 @@ struct DeviceBatch {
   int32_t* trace_len;   // [npairs]
   int32_t* complete;    // [npairs]
   int32_t* errflag;     // [1] sticky device-side error (team protocol timeout)
+  const int32_t* mu2_dense;  // dense-mu2 mode: mu2(k,l) tables (else nullptr: LOOKUP form)
   int32_t* prog;        // cross-CU teams: [pairs in launch][64] progress words, zeroed per launch
   int32_t team;         // cross-CU teams: workgroups (= waves) per pair
 };
@@ -195,6 +197,45 @@ struct GhostFeed {
   }
 };
 
+// ---------------------------------------------------------------------------
+// Dense-mu2 feed (structure similarities that are not a
+// small class table, e.g. from predicted base-pair probabilities).  A lane keeps the W
+// values mu2(k, j-s .. j+s) of its row in registers and needs ONE new value per step,
+// mu2(k, v+s) for the "virtual column" v that runs through the strip change (v = j, or
+// j - P once j+s has left the molecule: then the value already belongs to the next
+// strip's row).  Like the ghost feed, the values come by LDS-DMA one block of steps
+// ahead (global_load_lds_dword, per-lane source address, lane-linear destination).
+// ---------------------------------------------------------------------------
+template <int S>
+struct Mu2Feed {
+  static constexpr int BLK = GhostFeed<S, 9>::BLK;
+  static constexpr int RING_DW = 2 * BLK * 64;
+  // this lane's columns at the BLK steps of the block are jj0, jj0+1, ... (before wrapping)
+  __device__ static __forceinline__ void issue(const int32_t* tab, int n, int m, int P, int jj0,
+                                               int strip, int T, int w, int il, int aa,
+                                               uint32_t lds_base) {
+    constexpr int RR = Geo<S>::RR;
+#pragma unroll
+    for (int t = 0; t < BLK; ++t) {
+      int jf = jj0 + t, q = strip;
+      if (jf >= P) { jf -= P; ++q; }
+      int l = jf + S;
+      if (l > m) { l = jf - P + S; ++q; }  // already the next strip's row
+      const int k = (q * T + w) * RR + il - 1 + aa - S;
+      const int kc = min(max(k, 1), n), lc = min(max(l, 1), m);
+      const int32_t* p = tab + (int64_t)(kc - 1) * m + (lc - 1);
+      const uint32_t dst = lds_base + t * 256;  // lane l lands at dst + 4*l
+      uint32_t keep;
+      asm volatile(
+          "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+          "global_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+          : "=&s"(keep)
+          : "v"(p), "s"(dst)
+          : "memory");
+    }
+  }
+};
+
 __device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
 // f_T for the three target halves; arguments are the values for source half Y, X, M.
 __device__ __forceinline__ int fM(int y, int x, int m) { return imax(imax(y, x), m); }
@@ -255,7 +296,7 @@ __device__ __forceinline__ void store_chunk(int32_t* p, v4i v) {
     *reinterpret_cast<v4i*>(p) = v;
 }
 
-template <int S, bool BETA_NONPOS, int TW, bool XCU>
+template <int S, bool BETA_NONPOS, int TW, bool XCU, bool DENSE = false>
 __global__ void __launch_bounds__(64 * TW) fill_affine_kernel(const DeviceBatch A) {
   static_assert(!XCU || TW == 1, "cross-CU teams are built from one-wave workgroups");
   using G_ = Geo<S>;
@@ -282,10 +323,13 @@ __global__ void __launch_bounds__(64 * TW) fill_affine_kernel(const DeviceBatch 
   // ---- LDS carve-up: per wave a ghost ring and an exchange array; shared: progress
   //      words, score tables, sequence codes
   using GF = GhostFeed<S, 9>;
+  using MF = Mu2Feed<S>;
+  constexpr int PERW = GF::RING_DW + NV * NCOL + (DENSE ? MF::RING_DW : 0);  // dwords per wave
   v4i* ring = reinterpret_cast<v4i*>(smem + wl * GF::RING_DW);   // ghost-row ring, two halves
   int32_t* xch = smem + TW * GF::RING_DW + wl * (NV * NCOL);     // [NV][NCOL] exchange array
-  volatile int32_t* prog_lds = smem + TW * (GF::RING_DW + NV * NCOL);  // [16] (in-workgroup teams)
-  int32_t* s1 = smem + TW * (GF::RING_DW + NV * NCOL) + 16;      // [k1*k1]
+  int32_t* mu2ring = smem + TW * (GF::RING_DW + NV * NCOL) + wl * MF::RING_DW;  // dense-mu2 ring
+  volatile int32_t* prog_lds = smem + TW * PERW;                  // [16] (in-workgroup teams)
+  int32_t* s1 = smem + TW * PERW + 16;                            // [k1*k1]
   int32_t* s2 = s1 + k1 * k1;                                   // [k2*k2]
   const int npad = (n + 3) & ~3, mpad = (m + 2 * PADB + 3) & ~3;
   uint8_t* sa = reinterpret_cast<uint8_t*>(s2 + k2 * k2);  // seq A codes, [i-1]
@@ -293,7 +337,7 @@ __global__ void __launch_bounds__(64 * TW) fill_affine_kernel(const DeviceBatch 
   uint8_t* sb = ca + npad;                                  // seq B codes, [j-1+PADB]
   uint8_t* cb = sb + mpad;                                  // cls B,       [l-1+PADB]
 
-  for (int t = threadIdx.x; t < TW * (GF::RING_DW + NV * NCOL); t += 64 * TW) smem[t] = SENT;
+  for (int t = threadIdx.x; t < TW * PERW; t += 64 * TW) smem[t] = SENT;
   if (threadIdx.x < 16) prog_lds[threadIdx.x] = 0;
   for (int t = threadIdx.x; t < k1 * k1; t += 64 * TW) s1[t] = A.s1[t];
   for (int t = threadIdx.x; t < k2 * k2; t += 64 * TW) s2[t] = A.s2[t];
@@ -387,15 +431,24 @@ __global__ void __launch_bounds__(64 * TW) fill_affine_kernel(const DeviceBatch 
       __builtin_amdgcn_s_sleep(16);
     }
   };
-  auto prefetch_block = [&](int h0, int half) __attribute__((always_inline)) {
-    // h0 = first local step of the block; blk_q/blk_rem describe h0
+  const uint32_t mu2_lds = __builtin_amdgcn_readfirstlane(
+      (uint32_t)(uintptr_t)(__attribute__((address_space(3))) int32_t*)smem) +
+      (TW * (GF::RING_DW + NV * NCOL) + wl * MF::RING_DW) * 4;
+  const int32_t* const mu2tab = DENSE ? A.mu2_dense + pd.mu2_off : nullptr;
+  int mu2w[W];  // dense-mu2 mode: mu2(k, j-s .. j+s) of this lane's row
+#pragma unroll
+  for (int bb = 0; bb < W; ++bb) mu2w[bb] = 0;
+  auto prefetch_block = [&](int h0, int half, int jj0) __attribute__((always_inline)) {
+    // h0 = first local step of the block (this lane is then at column jj0, before wrapping);
+    // blk_q/blk_rem describe h0
     wait_partner(h0 + GF::BLK - 1);
     GF::issue(lay, h0, blk_q, blk_rem, P, T, w, GOFF, rec_last, L, ring_lds + half * GF::SLOTS * 16);
+    if (DENSE) MF::issue(mu2tab, n, m, P, jj0, strip, T, w, il, aa, mu2_lds + half * MF::BLK * 256);
     blk_rem += GF::BLK;
     if (blk_rem >= P) { blk_rem -= P; ++blk_q; }
   };
   // block 0 must be in the ring before the first step (waves w >= 1 start on a real ghost row)
-  prefetch_block(0, 0);
+  prefetch_block(0, 0, jj);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
   // One step of the sweep.  INTERIOR steps (every lane's lattice points have all
@@ -412,7 +465,7 @@ __global__ void __launch_bounds__(64 * TW) fill_affine_kernel(const DeviceBatch 
     if (gt == 0) {
       GF::wait_block();
       if ((XCU || TW > 1) && L == 0) prog_put(g - 8);  // <= 40 vector-memory ops pending = < 6 steps of stores
-      prefetch_block(g + GF::BLK, ghalf ^ 1);
+      prefetch_block(g + GF::BLK, ghalf ^ 1, jj + GF::BLK);
     }
     GF::fetch(ghostM, ring + ghalf * GF::SLOTS, gt, aa);
 
@@ -441,8 +494,16 @@ __global__ void __launch_bounds__(64 * TW) fill_affine_kernel(const DeviceBatch 
     const int jc = INTERIOR ? jj : min(max(jj, 0), m + 1);
     const int mu1 = s1[s1row + sb[jc - 1 + PADB]];
     int mu2[W];
+    if (DENSE) {  // slide the window, take this step's new value from the ring
 #pragma unroll
-    for (int bb = 0; bb < W; ++bb) mu2[bb] = s2[s2row + cb[jc + bb]];  // l-1+PADB = jc+bb
+      for (int bb = 0; bb + 1 < W; ++bb) mu2w[bb] = mu2w[bb + 1];
+      mu2w[W - 1] = mu2ring[(ghalf * MF::BLK + gt) * 64 + L];
+#pragma unroll
+      for (int bb = 0; bb < W; ++bb) mu2[bb] = mu2w[bb];
+    } else {
+#pragma unroll
+      for (int bb = 0; bb < W; ++bb) mu2[bb] = s2[s2row + cb[jc + bb]];  // l-1+PADB = jc+bb
+    }
 
     const bool tile_act = INTERIOR ? true : (act_row && jj >= 0 && jj <= m);
     const bool is_origin = INTERIOR ? false : (tile_act && i == 0 && jj == 0 && aa == S);
@@ -752,7 +813,10 @@ __global__ void __launch_bounds__(64) traceback_affine_kernel(const DeviceBatch 
     const int hU = st / 3, hV = st - 3 * hU;
     const int u0 = hU >= 1, u1 = hU != 1, v0 = hV >= 1, v1 = hV != 1;
     const int mu1 = (i >= 1 && j >= 1) ? in.s1[sa[i - 1] * A.k1 + sb[j - 1]] : 0;
-    const int mu2 = (k >= 1 && l >= 1) ? in.s2[ca[k - 1] * A.k2 + cb[l - 1]] : 0;
+    const int mu2 = (k >= 1 && l >= 1)
+                        ? (A.mu2_dense ? A.mu2_dense[pd.mu2_off + (int64_t)(k - 1) * m + (l - 1)]
+                                       : in.s2[ca[k - 1] * A.k2 + cb[l - 1]])
+                        : 0;
     const int valU = hU == 2 ? mu1 : gamma, valV = hV == 2 ? mu2 : gamma;
 
     // this lane's candidate: offset, source state, score (pyx:84-131)
@@ -806,7 +870,7 @@ __global__ void __launch_bounds__(64) traceback_affine_kernel(const DeviceBatch 
 // later and kept in registers for the cases that need them 2 or 3 steps later
 // (age of offset o = o0 + o1 + o2).
 // ---------------------------------------------------------------------------
-template <int S, int TW>
+template <int S, int TW, bool DENSE = false>
 __global__ void __launch_bounds__(64 * TW) fill_linear_kernel(const DeviceBatch A) {
   using G_ = Geo<S>;
   using R_ = Rec<S, 1>;
@@ -827,10 +891,13 @@ __global__ void __launch_bounds__(64 * TW) fill_linear_kernel(const DeviceBatch 
   const int gD = gamma + delta, gg = 2 * gamma;
 
   using GF = GhostFeed<S, 1>;
+  using MF = Mu2Feed<S>;
+  constexpr int PERW = GF::RING_DW + NV * NCOL + (DENSE ? MF::RING_DW : 0);
   v4i* ring = reinterpret_cast<v4i*>(smem + w * GF::RING_DW);
   int32_t* xch = smem + TW * GF::RING_DW + w * (NV * NCOL);
-  volatile int32_t* prog = smem + TW * (GF::RING_DW + NV * NCOL);  // [16] steps with acknowledged stores
-  int32_t* s1 = smem + TW * (GF::RING_DW + NV * NCOL) + 16;
+  int32_t* mu2ring = smem + TW * (GF::RING_DW + NV * NCOL) + w * MF::RING_DW;
+  volatile int32_t* prog = smem + TW * PERW;  // [16] steps with acknowledged stores
+  int32_t* s1 = smem + TW * PERW + 16;
   int32_t* s2 = s1 + k1 * k1;
   const int npad = (n + 3) & ~3, mpad = (m + 2 * PADB + 3) & ~3;
   uint8_t* sa = reinterpret_cast<uint8_t*>(s2 + k2 * k2);
@@ -838,7 +905,7 @@ __global__ void __launch_bounds__(64 * TW) fill_linear_kernel(const DeviceBatch 
   uint8_t* sb = ca + npad;
   uint8_t* cb = sb + mpad;
 
-  for (int t = threadIdx.x; t < TW * (GF::RING_DW + NV * NCOL); t += 64 * TW) smem[t] = SENT;
+  for (int t = threadIdx.x; t < TW * PERW; t += 64 * TW) smem[t] = SENT;
   if (threadIdx.x < 16) prog[threadIdx.x] = 0;
   for (int t = threadIdx.x; t < k1 * k1; t += 64 * TW) s1[t] = A.s1[t];
   for (int t = threadIdx.x; t < k2 * k2; t += 64 * TW) s2[t] = A.s2[t];
@@ -903,13 +970,21 @@ __global__ void __launch_bounds__(64 * TW) fill_linear_kernel(const DeviceBatch 
       __builtin_amdgcn_s_sleep(16);
     }
   };
-  auto prefetch_block = [&](int h0, int half) __attribute__((always_inline)) {
+  const uint32_t mu2_lds = __builtin_amdgcn_readfirstlane(
+      (uint32_t)(uintptr_t)(__attribute__((address_space(3))) int32_t*)smem) +
+      (TW * (GF::RING_DW + NV * NCOL) + w * MF::RING_DW) * 4;
+  const int32_t* const mu2tab = DENSE ? A.mu2_dense + pd.mu2_off : nullptr;
+  int mu2w[W];
+#pragma unroll
+  for (int bb = 0; bb < W; ++bb) mu2w[bb] = 0;
+  auto prefetch_block = [&](int h0, int half, int jj0) __attribute__((always_inline)) {
     wait_partner(h0 + GF::BLK - 1);
     GF::issue(lay, h0, blk_q, blk_rem, P, T, w, GOFF, rec_last, L, ring_lds + half * GF::SLOTS * 16);
+    if (DENSE) MF::issue(mu2tab, n, m, P, jj0, strip, T, w, il, aa, mu2_lds + half * MF::BLK * 256);
     blk_rem += GF::BLK;
     if (blk_rem >= P) { blk_rem -= P; ++blk_q; }
   };
-  prefetch_block(0, 0);
+  prefetch_block(0, 0, jj);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
   for (int g = 0; g < H; ++g) {
@@ -917,7 +992,7 @@ __global__ void __launch_bounds__(64 * TW) fill_linear_kernel(const DeviceBatch 
     if (gt == 0) {
       GF::wait_block();
       if (T > 1 && L == 0) prog[w] = g - 8;
-      prefetch_block(g + GF::BLK, ghalf ^ 1);
+      prefetch_block(g + GF::BLK, ghalf ^ 1, jj + GF::BLK);
     }
     GF::fetch(ghostM, ring + ghalf * GF::SLOTS, gt, aa);
     int inLW[W], inLW1[W], inL1[W];
@@ -930,8 +1005,16 @@ __global__ void __launch_bounds__(64 * TW) fill_linear_kernel(const DeviceBatch 
     const int jc = min(max(jj, 0), m + 1);
     const int mu1 = s1[s1row + sb[jc - 1 + PADB]];
     int mu2[W];
+    if (DENSE) {
 #pragma unroll
-    for (int bb = 0; bb < W; ++bb) mu2[bb] = s2[s2row + cb[jc + bb]];
+      for (int bb = 0; bb + 1 < W; ++bb) mu2w[bb] = mu2w[bb + 1];
+      mu2w[W - 1] = mu2ring[(ghalf * MF::BLK + gt) * 64 + L];
+#pragma unroll
+      for (int bb = 0; bb < W; ++bb) mu2[bb] = mu2w[bb];
+    } else {
+#pragma unroll
+      for (int bb = 0; bb < W; ++bb) mu2[bb] = s2[s2row + cb[jc + bb]];
+    }
 
     const bool tile_act = act_row && jj >= 0 && jj <= m;
     const bool is_origin = tile_act && i == 0 && jj == 0 && aa == S;
@@ -1040,7 +1123,10 @@ __global__ void __launch_bounds__(64) traceback_linear_kernel(const DeviceBatch 
   int i = n, j = m, k = n, l = m, len = 0;
   while (true) {
     const int mu1 = (i >= 1 && j >= 1) ? in.s1[sa[i - 1] * A.k1 + sb[j - 1]] : 0;
-    const int mu2 = (k >= 1 && l >= 1) ? in.s2[ca[k - 1] * A.k2 + cb[l - 1]] : 0;
+    const int mu2 = (k >= 1 && l >= 1)
+                        ? (A.mu2_dense ? A.mu2_dense[pd.mu2_off + (int64_t)(k - 1) * m + (l - 1)]
+                                       : in.s2[ca[k - 1] * A.k2 + cb[l - 1]])
+                        : 0;
     const int sc = kconst + (use1 ? mu1 : 0) + (use2 ? mu2 : 0);
     const int pi = i - o0, pj = j - o1, pk = k - o2, pl = l - o3;
     const bool ok = c < 13 && pi >= 0 && pj >= 0 && pk >= 0 && pl >= 0 && abs(pk - pi) <= S && abs(pl - pj) <= S;

@@ -56,10 +56,12 @@ class Batch:
 
     ``mols_a`` / ``mols_b``: lists of ``(seq_codes uint8[n], class_codes uint8[n])``.
     ``s1`` / ``s2``: int32 score tables (k1 x k1, k2 x k2).
+    ``mu2_dense``: optional list of int32 arrays, pair p's of shape (n_p, m_p) with entry
+    [k-1, l-1] = mu2(k, l); replaces the class codes / ``s2`` (DENSE form of include/bialign.h).
     """
 
     def __init__(self, engine, mols_a, mols_b, s1, s2, gap_opening_cost, gap_cost, shift_cost,
-                 max_shift, hbm_budget_bytes=0, recurrence=0):
+                 max_shift, hbm_budget_bytes=0, recurrence=0, mu2_dense=None):
         if len(mols_a) != len(mols_b) or not mols_a:
             raise ValueError("need the same, non-zero number of A and B molecules")
         self.engine = engine
@@ -83,13 +85,27 @@ class Batch:
             raise ValueError("sequence code outside the S1 table")
         if cls_a.size and (cls_a.max() >= s2.shape[0] or cls_b.max() >= s2.shape[0]):
             raise ValueError("structure class outside the S2 table")
+        mu2_ptr, mu2_off_ptr = None, None
+        if mu2_dense is not None:
+            if len(mu2_dense) != self.npairs:
+                raise ValueError("mu2_dense needs one table per pair")
+            flat = []
+            for p, tab in enumerate(mu2_dense):
+                tab = np.ascontiguousarray(tab, dtype=np.int32)
+                if tab.shape != (int(self.len_a[p]), int(self.len_b[p])):
+                    raise ValueError(f"mu2_dense[{p}] must have shape (len A, len B)")
+                flat.append(tab.ravel())
+            mu2_off = np.zeros(self.npairs, dtype=np.int64)
+            mu2_off[1:] = np.cumsum([f.size for f in flat[:-1]])
+            mu2_flat = np.ascontiguousarray(np.concatenate(flat))
+            mu2_ptr, mu2_off_ptr = _ptr(mu2_flat, ctypes.c_int32), _ptr(mu2_off, ctypes.c_int64)
         prm = _lib.Params(int(gap_opening_cost), int(gap_cost), int(shift_cost), int(max_shift),
                           int(recurrence))
         sc = _lib.Scoring(s1.shape[0], _ptr(s1, ctypes.c_int32), s2.shape[0], _ptr(s2, ctypes.c_int32))
         pr = _lib.Pairs(self.npairs, _ptr(self.len_a, ctypes.c_int32), _ptr(self.len_b, ctypes.c_int32),
                         _ptr(off_a, ctypes.c_int64), _ptr(off_b, ctypes.c_int64),
                         _ptr(seq_a, ctypes.c_uint8), _ptr(cls_a, ctypes.c_uint8),
-                        _ptr(seq_b, ctypes.c_uint8), _ptr(cls_b, ctypes.c_uint8))
+                        _ptr(seq_b, ctypes.c_uint8), _ptr(cls_b, ctypes.c_uint8), mu2_ptr, mu2_off_ptr)
         self._h = ctypes.c_void_p()
         check(lib.bialign_batch_create(engine._h, ctypes.byref(prm), ctypes.byref(sc), ctypes.byref(pr),
                                        int(hbm_budget_bytes), ctypes.byref(self._h)))

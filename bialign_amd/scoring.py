@@ -125,3 +125,19 @@ class ScoreModel:
 
     def mu2(self, cls_a, cls_b):
         return int(self.s2[cls_a, cls_b])
+
+
+def dense_mu2_from_features(mol_a, mol_b, structure_weight):
+    """int32 (n, m) table of the reference's RNA structure similarity for real-valued features
+    (predicted structures): int(sw * (sqrt(upA upB) + sqrt(dnA dnB) + sqrt(unpA unpB))), entry
+    [k-1, l-1] for k, l 1-based (pyx:416-423).  Same IEEE double operations in the same order as
+    the reference's per-cell Python expression; ``int()`` truncation = astype toward zero."""
+    terms = []
+    for key in ("up", "down", "unp"):
+        prod = np.multiply.outer(np.asarray(mol_a[key][1:], dtype=np.float64),
+                                 np.asarray(mol_b[key][1:], dtype=np.float64))
+        if (prod < 0).any():
+            raise ValueError("math domain error")  # math.sqrt of a negative product (pyx:419-421)
+        terms.append(np.sqrt(prod))
+    total = (terms[0] + terms[1]) + terms[2]
+    return np.trunc(structure_weight * total).astype(np.int32)

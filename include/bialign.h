@@ -18,6 +18,8 @@
  *     mu2(k,l) = s2[cls_a[k-1] * k2 + cls_b[l-1]]     (pyx:414-429, 438-440)
  * with uint8 codes prepared by the host side (bialign_amd/scoring.py).
  *
+ * or, for mu2 only, in DENSE form (bialign_pairs.mu2_dense).
+ *
  * The engine is GPU only.  There is no CPU fallback behind this ABI.
  */
 #ifndef BIALIGN_H
@@ -29,7 +31,7 @@
 extern "C" {
 #endif
 
-#define BIALIGN_ABI_VERSION 3
+#define BIALIGN_ABI_VERSION 4
 
 #define BIALIGN_OK 0
 #define BIALIGN_E_INVALID (-1)     /* bad argument (message says which) */
@@ -82,6 +84,13 @@ typedef struct bialign_pairs {
   const uint8_t* cls_a; /* structure classes, same indexing as seq_a */
   const uint8_t* seq_b;
   const uint8_t* cls_b;
+  /* Optional DENSE form of mu2 (NULL = LOOKUP form above): for structure similarities that are
+   * not a small class table -- the reference's RNA mode with *predicted* structures, where
+   * mu2(k,l) = int(sw*(sqrt(upA upB)+sqrt(dnA dnB)+sqrt(unpA unpB))) of real-valued features
+   * (pyx:416-423).  Pair p's table is mu2_dense[mu2_off[p] + (k-1)*m + (l-1)], k=1..n, l=1..m;
+   * cls_a / cls_b are then ignored (may be NULL). */
+  const int32_t* mu2_dense;
+  const int64_t* mu2_off;
 } bialign_pairs;
 
 typedef struct bialign_batch_info {

@@ -215,9 +215,14 @@ def band_values(layers, n, m, s):
 
 def solve(seqA, seqB, strA, strB, params, want_trace=True):
     """Whole reference hot path on the CPU: fill (+ traceback)."""
-    n, m, s = len(seqA), len(seqB), params["max_shift"]
-    beta, gamma, delta = params["gap_opening_cost"], params["gap_cost"], params["shift_cost"]
     mu1, mu2 = mu_tables(seqA, seqB, strA, strB, params)
+    return solve_tables(len(seqA), len(seqB), params, mu1, mu2, want_trace)
+
+
+def solve_tables(n, m, params, mu1, mu2, want_trace=True):
+    """Same, from explicit (n+1)x(m+1) mu1 / mu2 tables (real-valued RNA features, dense mu2)."""
+    s = params["max_shift"]
+    beta, gamma, delta = params["gap_opening_cost"], params["gap_cost"], params["shift_cost"]
     if beta != 0:
         score, layers = affine_fill(n, m, s, beta, gamma, delta, mu1, mu2)
         trace, ok = affine_traceback(n, m, s, beta, gamma, delta, mu1, mu2, layers) if want_trace else (None, True)

@@ -183,3 +183,27 @@ def test_missing_input_file_exits_like_the_intended_reference(capsys):
     with pytest.raises(SystemExit):
         ba.read_molecule_from_file("/nonexistent/file.cfssp", "Protein")
     assert "Input file not found." in capsys.readouterr().out
+
+
+# ---- real-valued RNA features -> dense mu2 table ---------------------------------------------
+FEATURES = load_golden("fractional_features.json")
+
+
+def feature_mol(feat):
+    return {k: feat[k] for k in ("up", "down", "unp")}
+
+
+@pytest.mark.parametrize("rec", FEATURES, ids=[r["name"] for r in FEATURES])
+def test_dense_mu2_from_features_equals_reference_mu2(rec):
+    """The vectorised sqrt / sum / truncation reproduces the reference's per-cell int(...) exactly."""
+    tab = scoring.dense_mu2_from_features(feature_mol(rec["featuresA"]), feature_mol(rec["featuresB"]),
+                                          rec["params"]["structure_weight"])
+    assert tab.dtype == np.int32
+    np.testing.assert_array_equal(tab, np.array(rec["mu2"], dtype=np.int32))
+
+
+def test_dense_mu2_negative_product_raises_like_math_sqrt():
+    a = dict(up=[0, 0.5], down=[0, 0.6], unp=[0, 1.0 - 0.5 - 0.6])
+    b = dict(up=[0, 0.2], down=[0, 0.2], unp=[0, 0.6])
+    with pytest.raises(ValueError):
+        scoring.dense_mu2_from_features(a, b, 400)

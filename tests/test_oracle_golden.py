@@ -52,3 +52,30 @@ def test_empty_sequence_rejected():
     mu = np.zeros((1, 3), dtype=np.int32)
     with pytest.raises(ValueError):
         oracle.affine_fill(0, 2, 1, -150, -50, -150, mu, mu)
+
+
+# ---- real-valued RNA features (the reference's predicted-structure scoring) ------------------
+FEATURES = load_golden("fractional_features.json")
+
+
+def feature_tables(rec):
+    """mu1 from the oracle's own table builder, mu2 = the table the reference returned."""
+    n, m = len(rec["seqA"]), len(rec["seqB"])
+    mu1, _ = oracle.mu_tables(rec["seqA"], rec["seqB"], rec["strA"], rec["strB"], rec["params"])
+    mu2 = np.zeros((n + 1, m + 1), dtype=np.int32)
+    mu2[1:, 1:] = np.array(rec["mu2"], dtype=np.int32)
+    return mu1, mu2
+
+
+@pytest.mark.parametrize("rec", FEATURES, ids=[r["name"] for r in FEATURES])
+def test_fractional_feature_cases(rec):
+    n, m, p = len(rec["seqA"]), len(rec["seqB"]), rec["params"]
+    mu1, mu2 = feature_tables(rec)
+    res = oracle.solve_tables(n, m, p, mu1, mu2)
+    assert res["score"] == rec["score"]
+    assert oracle.trace_to_lists(res["trace"]) == rec["trace"]
+    assert res["complete"] == rec["complete"]
+    if "layers" in rec:
+        got = oracle.band_values(res["layers"], n, m, p["max_shift"])
+        for g, e in zip(got, rec["layers"]):
+            np.testing.assert_array_equal(g, np.array(e, dtype=np.int64))
