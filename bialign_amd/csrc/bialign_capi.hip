@@ -716,7 +716,7 @@ int bialign_batch_dump_layers(bialign_batch* b, int32_t pair, int32_t* out) {
   if (rc) return rc;
   HIP_TRY(hipMemcpyAsync(out, d_out.p, elems * sizeof(int32_t), hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
-  b->ran = false;  // the resident chunk's layers were overwritten
+  // scores and traces live in their own buffers and stay valid; only the layer region was rewritten
   return check_device_error(b);
 }
 

@@ -126,7 +126,7 @@ def test_dense_ragged_batch_and_chunking():
     for params in (dict(synth.PROTEIN_PARAMS), dict(synth.PROTEIN_PARAMS, max_shift=2, **LIN)):
         for budget in (0, 5 << 20):
             got = dense_solve(pairs, tabs, params, budget=budget)
-            if budget:
+            if budget and params["gap_opening_cost"]:
                 assert got["info"]["nchunks"] > 1
             for t, pair in enumerate(pairs):
                 ref = oracle_dense(pair, tabs[t], params)
@@ -165,7 +165,8 @@ def test_dense_equals_class_form_on_the_same_scores():
     tab = np.array([[sw if x == y else 0 for y in pair[3]] for x in pair[2]], dtype=np.int32)
     b = make_batch([pair], params)
     b.run()
-    want = b.dump_layers(0), int(b.scores()[0]), b.traces()[0][0].tolist()
+    score = int(b.scores()[0])
+    want = b.dump_layers(0), score
     b.close()
     got = dense_solve([pair], [tab], params, layers_of=0)
     np.testing.assert_array_equal(got["layers"], want[0])
