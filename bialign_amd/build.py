@@ -1,15 +1,24 @@
-"""Build libbialign_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
+"""Build libbialign_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU).
+
+The kernels are templates on max_shift; each (max_shift, kind) slice is its own translation unit
+(csrc/bialign_inst.hip with -DBIALIGN_TU_S / -DBIALIGN_TU_KIND), compiled in parallel, then linked
+with the C-ABI unit (csrc/bialign_capi.hip) into one shared library.
+"""
+import concurrent.futures
 import os
 import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SRC = os.path.join(HERE, "csrc", "bialign_capi.hip")
-DEPS = [SRC, os.path.join(HERE, "csrc", "bialign_kernels.hpp"),
-        os.path.join(os.path.dirname(HERE), "include", "bialign.h")]
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(CSRC, "build")
+DEPS = [os.path.join(CSRC, f) for f in ("bialign_capi.hip", "bialign_inst.hip", "bialign_host.hpp",
+                                        "bialign_kernels.hpp")]
+DEPS.append(os.path.join(os.path.dirname(HERE), "include", "bialign.h"))
 OUT = os.path.join(HERE, "libbialign_hip.so")
-HOST_SRC = os.path.join(HERE, "csrc", "bialign_host.c")
+HOST_SRC = os.path.join(CSRC, "bialign_host.c")
 HOST_OUT = os.path.join(HERE, "libbialign_host.so")
+MAX_SHIFT = 5
 
 
 def build_host(force=False):
@@ -19,16 +28,39 @@ def build_host(force=False):
     return HOST_OUT
 
 
-def build(force=False, verbose=False):
+def units():
+    """(object name, source, extra flags), the slow ones (affine fill, wide bands) first."""
+    out = [(f"inst_s{s}_k0.o", "bialign_inst.hip", [f"-DBIALIGN_TU_S={s}", "-DBIALIGN_TU_KIND=0"])
+           for s in range(MAX_SHIFT, -1, -1)]
+    out += [(f"inst_s{s}_k1.o", "bialign_inst.hip", [f"-DBIALIGN_TU_S={s}", "-DBIALIGN_TU_KIND=1"])
+            for s in range(MAX_SHIFT, -1, -1)]
+    out.append(("capi.o", "bialign_capi.hip", []))
+    return out
+
+
+def build(force=False, verbose=False, out=OUT, defines=(), jobs=None):
     build_host(force)
-    if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in DEPS):
-        return OUT
+    if not force and not defines and os.path.exists(out) and \
+            all(os.path.getmtime(out) >= os.path.getmtime(d) for d in DEPS):
+        return out
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", OUT, SRC]
+    objdir = OBJ if out == OUT else out + ".obj"
+    os.makedirs(objdir, exist_ok=True)
+    base = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"] + [f"-D{d}" for d in defines]
     if verbose:
-        cmd.append("-Rpass-analysis=kernel-resource-usage")
-    subprocess.run(cmd, check=True)
-    return OUT
+        base.append("-Rpass-analysis=kernel-resource-usage")
+
+    def compile_one(unit):
+        obj, src, flags = unit
+        subprocess.run(base + flags + ["-c", os.path.join(CSRC, src), "-o", os.path.join(objdir, obj)],
+                       check=True)
+        return os.path.join(objdir, obj)
+
+    jobs = jobs or min(8, os.cpu_count() or 1)
+    with concurrent.futures.ThreadPoolExecutor(max_workers=jobs) as pool:
+        objs = list(pool.map(compile_one, units()))
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs, check=True)
+    return out
 
 
 if __name__ == "__main__":

@@ -4,25 +4,13 @@
 // HBM-budgeted chunks, launch fill + traceback per chunk on the engine's
 // stream, time the kernels with HIP events, hand results back.  No CPU compute
 // path exists here: if the device or a kernel is unavailable the call fails.
-#include "bialign_kernels.hpp"
-
-#include <algorithm>
-#include <cstdarg>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <memory>
-#include <numeric>
-#include <string>
-#include <vector>
-
-#include "../../include/bialign.h"
+#include "bialign_host.hpp"
 
 using namespace bialign;
 
-namespace {
+namespace bialign {
 
-thread_local std::string g_err;
+static thread_local std::string g_err;
 
 int fail(int code, const char* fmt, ...) {
   char buf[512];
@@ -32,154 +20,6 @@ int fail(int code, const char* fmt, ...) {
   va_end(ap);
   g_err = buf;
   return code;
-}
-
-#define HIP_TRY(expr)                                                                 \
-  do {                                                                                \
-    hipError_t e_ = (expr);                                                           \
-    if (e_ != hipSuccess)                                                             \
-      return fail(BIALIGN_E_DEVICE, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
-                  __FILE__, __LINE__);                                                \
-  } while (0)
-
-template <typename T>
-struct DevBuf {
-  T* p = nullptr;
-  size_t n = 0;
-  ~DevBuf() { release(); }
-  void release() {
-    if (p) (void)hipFree(p);
-    p = nullptr;
-    n = 0;
-  }
-  hipError_t alloc(size_t count) {
-    release();
-    n = count;
-    return hipMalloc(reinterpret_cast<void**>(&p), std::max<size_t>(count, 1) * sizeof(T));
-  }
-  hipError_t upload(const T* src, size_t count, hipStream_t s) {
-    hipError_t e = alloc(count);
-    if (e != hipSuccess || count == 0) return e;
-    return hipMemcpyAsync(p, src, count * sizeof(T), hipMemcpyHostToDevice, s);
-  }
-};
-
-// GhostFeed<S,.>::BLK
-int ghost_blk(int S) {
-#ifdef BIALIGN_BLK_OVERRIDE
-  (void)S;
-  return BIALIGN_BLK_OVERRIDE;
-#else
-  return S <= 2 ? 8 : 4;
-#endif
-}
-
-// Sweep geometry of one pair (mirrors the kernel's Geo<S>): strips, period, steps.
-void sweep_geometry(int n, int m, int S, int* NS, int* P, int* G) {
-  const int W = 2 * S + 1, R = 64 / W, RR = R - 1;
-  const int min_goff = 2 * ghost_blk(S) + 8;  // GhostFeed<S,.>::MIN_GOFF
-  *NS = (n + 1 + RR - 1) / RR;
-  // one idle column between strips (P >= m+2) and ghost records old enough to prefetch
-  *P = std::max(m + 2, 2 * (R - 1) + min_goff);
-  *G = (*NS - 1) * *P + m + 2 * (R - 1) + (W - 1) + 1;
-}
-
-int64_t cells_of(int n, int m, int s) {
-  auto K = [s](int x) {
-    int64_t t = 0;
-    for (int i = 0; i <= x; ++i) t += std::min(x, i + s) - std::max(0, i - s) + 1;
-    return t;
-  };
-  return K(n) * K(m);
-}
-
-}  // namespace
-
-struct bialign_engine {
-  int device = 0;
-  int num_cu = 256;
-  hipStream_t stream = nullptr;
-  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
-};
-
-struct bialign_batch {
-  bialign_engine* eng = nullptr;
-  bialign_params prm{};
-  int affine = 0, NL = 1, S = 0;
-  int npairs = 0;
-  std::vector<PairDesc> pairs;      // host mirror (layer_off valid for the pair's chunk)
-  std::vector<int32_t> order;       // chunk-by-chunk launch order
-  std::vector<int> chunk_begin;     // index into order, size nchunks+1
-  int64_t cells = 0, trace_bytes = 0, max_chunk_dwords = 0;
-  size_t lds_bytes = 0;                   // dynamic LDS of a one-wave workgroup
-  size_t lds_base = 0, lds_per_wave = 0;  // team launches: lds_base + T * lds_per_wave
-  size_t lds_trace = 0;                   // tracebacks: score tables + sequence codes
-  DevBuf<PairDesc> d_pairs;
-  DevBuf<int32_t> d_order, d_s1, d_s2, d_layers, d_scores, d_tlen, d_complete, d_err, d_prog;
-  int last_team = 1;  // waves per pair of the last fill launch (negative: cross-CU team)
-  DevBuf<uint8_t> d_seq_a, d_cls_a, d_seq_b, d_cls_b, d_trace;
-  DevBuf<int32_t> d_mu2;  // dense-mu2 mode: all pairs' n x m tables
-  bool dense = false;
-  int k1 = 0, k2 = 0;
-  bialign_timing timing{};
-  bool ran = false, ran_trace = false;
-
-  DeviceBatch view() const {
-    DeviceBatch v{};
-    v.pairs = d_pairs.p;
-    v.order = d_order.p;
-    v.seq_a = d_seq_a.p; v.cls_a = d_cls_a.p; v.seq_b = d_seq_b.p; v.cls_b = d_cls_b.p;
-    v.s1 = d_s1.p; v.s2 = d_s2.p;
-    v.k1 = k1; v.k2 = k2;
-    v.beta = prm.gap_opening_cost; v.gamma = prm.gap_cost; v.delta = prm.shift_cost;
-    v.layers = d_layers.p;
-    v.scores = d_scores.p;
-    v.trace = d_trace.p;
-    v.trace_len = d_tlen.p;
-    v.complete = d_complete.p;
-    v.errflag = d_err.p;
-    v.mu2_dense = dense ? d_mu2.p : nullptr;
-    return v;
-  }
-};
-
-namespace {
-
-size_t lds_need(int S, int NL, int team, int k1, int k2, int n, int m, bool dense = false) {
-  const int W = 2 * S + 1, PADB = S + 1;
-  const size_t nv = (NL == 9 ? 12 : 1) * W;
-  const size_t npad = (n + 3) & ~3, mpad = (m + 2 * PADB + 3) & ~3;
-  const int nd = NL * W, np = nd / 4 + (nd % 4 ? 1 : 0), blk = ghost_blk(S);
-  const size_t ring_dw = 2 * (((size_t)blk * W * np + 63) / 64 * 64) * 4;  // GhostFeed<S,NL>::RING_DW
-  const size_t shared_dw = 16 + (size_t)k1 * k1 + (size_t)k2 * k2;  // progress words + score tables
-  const size_t mu2_ring_dw = dense ? 2 * (size_t)blk * 64 : 0;  // Mu2Feed<S>::RING_DW
-  return (team * (ring_dw + nv * NCOL + mu2_ring_dw) + shared_dw) * 4 + 2 * npad + 2 * mpad;
-}
-
-// One launch shape: TW waves per workgroup, GW workgroups per pair (GW > 1 = cross-CU team).
-struct TeamShape {
-  int tw = 1, gw = 1;
-  int waves() const { return tw * gw; }
-};
-
-template <int S, bool BETA_NONPOS, int TW, bool XCU, bool DENSE = false>
-int launch_fill_affine_t(bialign_batch* b, const DeviceBatch& v, int first, int count, int gw) {
-  DeviceBatch w = v;
-  w.order = v.order + first;
-  w.team = gw;
-  auto kern = fill_affine_kernel<S, BETA_NONPOS, TW, XCU, DENSE>;
-  const size_t lds = b->lds_base + (size_t)TW * b->lds_per_wave;
-  if (lds > 64 * 1024)
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  if (XCU) {
-    if (b->d_prog.n < (size_t)count * 64) HIP_TRY(b->d_prog.alloc((size_t)count * 64));
-    HIP_TRY(hipMemsetAsync(b->d_prog.p, 0, (size_t)count * 64 * sizeof(int32_t), b->eng->stream));
-    w.prog = b->d_prog.p;
-  }
-  hipLaunchKernelGGL(kern, dim3(count * (XCU ? gw : 1)), dim3(64 * TW), lds, b->eng->stream, w);
-  HIP_TRY(hipGetLastError());
-  return BIALIGN_OK;
 }
 
 // Waves per pair.  More waves per pair = more waves per SIMD when a launch has fewer pairs than
@@ -248,96 +88,38 @@ TeamShape team_shape(const bialign_batch* b, int first, int count) {
   return ts;
 }
 
-template <int S>
-int launch_fill_affine(bialign_batch* b, const DeviceBatch& v, int first, int count) {
-  if (b->prm.gap_opening_cost > 0) {  // rare: general-beta algebra, one wave per pair
-    b->last_team = 1;
-    return b->dense ? launch_fill_affine_t<S, false, 1, false, true>(b, v, first, count, 1)
-                    : launch_fill_affine_t<S, false, 1, false>(b, v, first, count, 1);
-  }
-  const TeamShape ts = team_shape(b, first, count);
-  b->last_team = ts.waves() * (ts.gw > 1 ? -1 : 1);
-  if (b->dense) {
-    if constexpr (S <= 3) {
-      if (ts.tw >= 2) return launch_fill_affine_t<S, true, 2, false, true>(b, v, first, count, 1);
-    }
-    b->last_team = 1;
-    return launch_fill_affine_t<S, true, 1, false, true>(b, v, first, count, 1);
-  }
-  if constexpr (S <= 3) {
-    if (ts.gw > 1) return launch_fill_affine_t<S, true, 1, true>(b, v, first, count, ts.gw);
-  }
-  if constexpr (S <= 1) {
-    if (ts.tw == 8) return launch_fill_affine_t<S, true, 8, false>(b, v, first, count, 1);
-  }
-  if constexpr (S <= 3) {  // s >= 4 needs nearly all 512 registers of a SIMD lane: one wave per pair
-    if (ts.tw >= 4) return launch_fill_affine_t<S, true, 4, false>(b, v, first, count, 1);
-    if (ts.tw >= 2) return launch_fill_affine_t<S, true, 2, false>(b, v, first, count, 1);
-  }
-  return launch_fill_affine_t<S, true, 1, false>(b, v, first, count, 1);
+}  // namespace bialign
+
+namespace {
+
+// Sweep geometry of one pair (mirrors the kernel's Geo<S>): strips, period, steps.
+void sweep_geometry(int n, int m, int S, int* NS, int* P, int* G) {
+  const int W = 2 * S + 1, R = 64 / W, RR = R - 1;
+  const int min_goff = 2 * ghost_blk(S) + 8;  // GhostFeed<S,.>::MIN_GOFF
+  *NS = (n + 1 + RR - 1) / RR;
+  // one idle column between strips (P >= m+2) and ghost records old enough to prefetch
+  *P = std::max(m + 2, 2 * (R - 1) + min_goff);
+  *G = (*NS - 1) * *P + m + 2 * (R - 1) + (W - 1) + 1;
 }
 
-template <int S>
-int launch_traceback_affine(const bialign_batch* b, const DeviceBatch& v, int first, int count,
-                            bool do_trace) {
-  DeviceBatch w = v;
-  w.order = v.order + first;
-  const int blocks = count;  // one wave per pair
-  if (b->lds_trace > 64 * 1024)
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(traceback_affine_kernel<S, true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_trace));
-  if (do_trace)
-    hipLaunchKernelGGL((traceback_affine_kernel<S, true>), dim3(blocks), dim3(64), b->lds_trace, b->eng->stream, w, count);
-  else
-    hipLaunchKernelGGL((traceback_affine_kernel<S, false>), dim3(blocks), dim3(64), 0, b->eng->stream, w, count);
-  HIP_TRY(hipGetLastError());
-  return BIALIGN_OK;
+int64_t cells_of(int n, int m, int s) {
+  auto K = [s](int x) {
+    int64_t t = 0;
+    for (int i = 0; i <= x; ++i) t += std::min(x, i + s) - std::max(0, i - s) + 1;
+    return t;
+  };
+  return K(n) * K(m);
 }
 
-template <int S, int TW, bool DENSE = false>
-int launch_fill_linear_t(bialign_batch* b, const DeviceBatch& v, int first, int count) {
-  DeviceBatch w = v;
-  w.order = v.order + first;
-  auto kern = fill_linear_kernel<S, TW, DENSE>;
-  const size_t lds = b->lds_base + (size_t)TW * b->lds_per_wave;
-  if (lds > 64 * 1024)
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(kern, dim3(count), dim3(64 * TW), lds, b->eng->stream, w);
-  HIP_TRY(hipGetLastError());
-  return BIALIGN_OK;
-}
-
-template <int S>
-int launch_fill_linear(bialign_batch* b, const DeviceBatch& v, int first, int count) {
-  const TeamShape ts = team_shape(b, first, count);
-  b->last_team = ts.tw;
-  if (b->dense)
-    return ts.tw >= 2 ? launch_fill_linear_t<S, 2, true>(b, v, first, count)
-                      : launch_fill_linear_t<S, 1, true>(b, v, first, count);
-  switch (ts.tw) {
-    case 8: return launch_fill_linear_t<S, 8>(b, v, first, count);
-    case 4: return launch_fill_linear_t<S, 4>(b, v, first, count);
-    case 2: return launch_fill_linear_t<S, 2>(b, v, first, count);
-    default: return launch_fill_linear_t<S, 1>(b, v, first, count);
-  }
-}
-
-template <int S>
-int launch_traceback_linear(const bialign_batch* b, const DeviceBatch& v, int first, int count,
-                            bool do_trace) {
-  DeviceBatch w = v;
-  w.order = v.order + first;
-  const int blocks = count;  // one wave per pair
-  if (b->lds_trace > 64 * 1024)
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(traceback_linear_kernel<S, true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_trace));
-  if (do_trace)
-    hipLaunchKernelGGL((traceback_linear_kernel<S, true>), dim3(blocks), dim3(64), b->lds_trace, b->eng->stream, w, count);
-  else
-    hipLaunchKernelGGL((traceback_linear_kernel<S, false>), dim3(blocks), dim3(64), 0, b->eng->stream, w, count);
-  HIP_TRY(hipGetLastError());
-  return BIALIGN_OK;
+size_t lds_need(int S, int NL, int team, int k1, int k2, int n, int m, bool dense = false) {
+  const int W = 2 * S + 1, PADB = S + 1;
+  const size_t nv = (NL == 9 ? 12 : 1) * W;
+  const size_t npad = (n + 3) & ~3, mpad = (m + 2 * PADB + 3) & ~3;
+  const int nd = NL * W, np = nd / 4 + (nd % 4 ? 1 : 0), blk = ghost_blk(S);
+  const size_t ring_dw = 2 * (((size_t)blk * W * np + 63) / 64 * 64) * 4;  // GhostFeed<S,NL>::RING_DW
+  const size_t shared_dw = 16 + (size_t)k1 * k1 + (size_t)k2 * k2;  // progress words + score tables
+  const size_t mu2_ring_dw = dense ? 2 * (size_t)blk * 64 : 0;  // Mu2Feed<S>::RING_DW
+  return (team * (ring_dw + nv * NCOL + mu2_ring_dw) + shared_dw) * 4 + 2 * npad + 2 * mpad;
 }
 
 int launch_fill(bialign_batch* b, const DeviceBatch& v, int first, int count) {
@@ -384,13 +166,6 @@ int launch_traceback(const bialign_batch* b, const DeviceBatch& v, int first, in
     }
   }
   return fail(BIALIGN_E_UNSUPPORTED, "no traceback kernel for affine=%d max_shift=%d", b->affine, b->S);
-}
-
-template <int S, int NL>
-int launch_dump(const bialign_batch* b, const DeviceBatch& v, int pid, int32_t* d_out) {
-  hipLaunchKernelGGL((dump_layers_kernel<S, NL>), dim3(256), dim3(256), 0, b->eng->stream, v, pid, d_out);
-  HIP_TRY(hipGetLastError());
-  return BIALIGN_OK;
 }
 
 int launch_dump_any(const bialign_batch* b, const DeviceBatch& v, int pid, int32_t* d_out) {
@@ -602,6 +377,8 @@ int bialign_batch_create(bialign_engine* eng, const bialign_params* prm, const b
   HIP_TRY(b->d_cls_b.upload(b->dense ? zeros.data() : pr->cls_b, tot_b, st));
   if (b->dense) HIP_TRY(b->d_mu2.upload(pr->mu2_dense, (size_t)tot_mu2, st));
   HIP_TRY(b->d_layers.alloc(b->max_chunk_dwords + 16));  // slack: ghost tail pieces are read 16 B wide
+  if (getenv("BIALIGN_DEBUG"))
+    fprintf(stderr, "[bialign] layers %p (%.1f GiB)\n", (void*)b->d_layers.p, b->max_chunk_dwords * 4.0 / (1 << 30));
   HIP_TRY(b->d_scores.alloc(pr->npairs));
   HIP_TRY(b->d_tlen.alloc(pr->npairs));
   HIP_TRY(b->d_complete.alloc(pr->npairs));

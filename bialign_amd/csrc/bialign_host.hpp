@@ -1,0 +1,263 @@
+// bialign_host.hpp -- host-side internals shared by the translation units of libbialign_hip.so:
+// the batch / engine objects behind the C ABI and the kernel launchers.  The launchers are
+// templates on max_shift; each (max_shift, kind) is instantiated in its own translation unit
+// (bialign_inst.hip, compiled once per -DBIALIGN_TU_S / -DBIALIGN_TU_KIND) so that the kernels
+// build in parallel; bialign_capi.hip only dispatches.
+#pragma once
+#include "bialign_kernels.hpp"
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "../../include/bialign.h"
+
+namespace bialign {
+
+int fail(int code, const char* fmt, ...);  // records the message bialign_last_error() returns
+
+#define HIP_TRY(expr)                                                                 \
+  do {                                                                                \
+    hipError_t e_ = (expr);                                                           \
+    if (e_ != hipSuccess)                                                             \
+      return fail(BIALIGN_E_DEVICE, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                  __FILE__, __LINE__);                                                \
+  } while (0)
+
+template <typename T>
+struct DevBuf {
+  T* p = nullptr;
+  size_t n = 0;
+  ~DevBuf() { release(); }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    n = 0;
+  }
+  hipError_t alloc(size_t count) {
+    release();
+    n = count;
+    return hipMalloc(reinterpret_cast<void**>(&p), std::max<size_t>(count, 1) * sizeof(T));
+  }
+  hipError_t upload(const T* src, size_t count, hipStream_t s) {
+    hipError_t e = alloc(count);
+    if (e != hipSuccess || count == 0) return e;
+    return hipMemcpyAsync(p, src, count * sizeof(T), hipMemcpyHostToDevice, s);
+  }
+};
+
+// GhostFeed<S,.>::BLK
+inline int ghost_blk(int S) {
+#ifdef BIALIGN_BLK_OVERRIDE
+  (void)S;
+  return BIALIGN_BLK_OVERRIDE;
+#else
+  return S <= 2 ? 8 : 4;
+#endif
+}
+
+}  // namespace bialign
+
+using bialign::DevBuf;
+using bialign::DeviceBatch;
+using bialign::PairDesc;
+
+struct bialign_engine {
+  int device = 0;
+  int num_cu = 256;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+};
+
+struct bialign_batch {
+  bialign_engine* eng = nullptr;
+  bialign_params prm{};
+  int affine = 0, NL = 1, S = 0;
+  int npairs = 0;
+  std::vector<PairDesc> pairs;      // host mirror (layer_off valid for the pair's chunk)
+  std::vector<int32_t> order;       // chunk-by-chunk launch order
+  std::vector<int> chunk_begin;     // index into order, size nchunks+1
+  int64_t cells = 0, trace_bytes = 0, max_chunk_dwords = 0;
+  size_t lds_bytes = 0;                   // dynamic LDS of a one-wave workgroup
+  size_t lds_base = 0, lds_per_wave = 0;  // team launches: lds_base + T * lds_per_wave
+  size_t lds_trace = 0;                   // tracebacks: score tables + sequence codes
+  DevBuf<PairDesc> d_pairs;
+  DevBuf<int32_t> d_order, d_s1, d_s2, d_layers, d_scores, d_tlen, d_complete, d_err, d_prog;
+  int last_team = 1;  // waves per pair of the last fill launch (negative: cross-CU team)
+  DevBuf<uint8_t> d_seq_a, d_cls_a, d_seq_b, d_cls_b, d_trace;
+  DevBuf<int32_t> d_mu2;  // dense-mu2 mode: all pairs' n x m tables
+  bool dense = false;
+  int k1 = 0, k2 = 0;
+  bialign_timing timing{};
+  bool ran = false, ran_trace = false;
+
+  DeviceBatch view() const {
+    DeviceBatch v{};
+    v.pairs = d_pairs.p;
+    v.order = d_order.p;
+    v.seq_a = d_seq_a.p; v.cls_a = d_cls_a.p; v.seq_b = d_seq_b.p; v.cls_b = d_cls_b.p;
+    v.s1 = d_s1.p; v.s2 = d_s2.p;
+    v.k1 = k1; v.k2 = k2;
+    v.beta = prm.gap_opening_cost; v.gamma = prm.gap_cost; v.delta = prm.shift_cost;
+    v.layers = d_layers.p;
+    v.scores = d_scores.p;
+    v.trace = d_trace.p;
+    v.trace_len = d_tlen.p;
+    v.complete = d_complete.p;
+    v.errflag = d_err.p;
+    v.mu2_dense = dense ? d_mu2.p : nullptr;
+    return v;
+  }
+};
+
+namespace bialign {
+
+// One launch shape: TW waves per workgroup, GW workgroups per pair (GW > 1 = cross-CU team).
+struct TeamShape {
+  int tw = 1, gw = 1;
+  int waves() const { return tw * gw; }
+};
+
+TeamShape team_shape(const bialign_batch* b, int first, int count);
+
+template <int S, bool BETA_NONPOS, int TW, bool XCU, bool DENSE = false>
+int launch_fill_affine_t(bialign_batch* b, const DeviceBatch& v, int first, int count, int gw) {
+  DeviceBatch w = v;
+  w.order = v.order + first;
+  w.team = gw;
+  auto kern = fill_affine_kernel<S, BETA_NONPOS, TW, XCU, DENSE>;
+  const size_t lds = b->lds_base + (size_t)TW * b->lds_per_wave;
+  if (lds > 64 * 1024)
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  if (XCU) {
+    if (b->d_prog.n < (size_t)count * 64) HIP_TRY(b->d_prog.alloc((size_t)count * 64));
+    HIP_TRY(hipMemsetAsync(b->d_prog.p, 0, (size_t)count * 64 * sizeof(int32_t), b->eng->stream));
+    w.prog = b->d_prog.p;
+  }
+  hipLaunchKernelGGL(kern, dim3(count * (XCU ? gw : 1)), dim3(64 * TW), lds, b->eng->stream, w);
+  HIP_TRY(hipGetLastError());
+  return BIALIGN_OK;
+}
+
+template <int S>
+int launch_fill_affine(bialign_batch* b, const DeviceBatch& v, int first, int count) {
+  if (b->prm.gap_opening_cost > 0) {  // rare: general-beta algebra, one wave per pair
+    b->last_team = 1;
+    return b->dense ? launch_fill_affine_t<S, false, 1, false, true>(b, v, first, count, 1)
+                    : launch_fill_affine_t<S, false, 1, false>(b, v, first, count, 1);
+  }
+  const TeamShape ts = team_shape(b, first, count);
+  b->last_team = ts.waves() * (ts.gw > 1 ? -1 : 1);
+  if (b->dense) {
+    if constexpr (S <= 3) {
+      if (ts.tw >= 2) return launch_fill_affine_t<S, true, 2, false, true>(b, v, first, count, 1);
+    }
+    b->last_team = 1;
+    return launch_fill_affine_t<S, true, 1, false, true>(b, v, first, count, 1);
+  }
+  if constexpr (S <= 3) {
+    if (ts.gw > 1) return launch_fill_affine_t<S, true, 1, true>(b, v, first, count, ts.gw);
+  }
+  if constexpr (S <= 1) {
+    if (ts.tw == 8) return launch_fill_affine_t<S, true, 8, false>(b, v, first, count, 1);
+  }
+  if constexpr (S <= 3) {  // s >= 4 needs nearly all 512 registers of a SIMD lane: one wave per pair
+    if (ts.tw >= 4) return launch_fill_affine_t<S, true, 4, false>(b, v, first, count, 1);
+    if (ts.tw >= 2) return launch_fill_affine_t<S, true, 2, false>(b, v, first, count, 1);
+  }
+  return launch_fill_affine_t<S, true, 1, false>(b, v, first, count, 1);
+}
+
+template <int S>
+int launch_traceback_affine(const bialign_batch* b, const DeviceBatch& v, int first, int count,
+                            bool do_trace) {
+  DeviceBatch w = v;
+  w.order = v.order + first;
+  const int blocks = count;  // one wave per pair
+  if (b->lds_trace > 64 * 1024)
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(traceback_affine_kernel<S, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_trace));
+  if (do_trace)
+    hipLaunchKernelGGL((traceback_affine_kernel<S, true>), dim3(blocks), dim3(64), b->lds_trace, b->eng->stream, w, count);
+  else
+    hipLaunchKernelGGL((traceback_affine_kernel<S, false>), dim3(blocks), dim3(64), 0, b->eng->stream, w, count);
+  HIP_TRY(hipGetLastError());
+  return BIALIGN_OK;
+}
+
+template <int S, int TW, bool DENSE = false>
+int launch_fill_linear_t(bialign_batch* b, const DeviceBatch& v, int first, int count) {
+  DeviceBatch w = v;
+  w.order = v.order + first;
+  auto kern = fill_linear_kernel<S, TW, DENSE>;
+  const size_t lds = b->lds_base + (size_t)TW * b->lds_per_wave;
+  if (lds > 64 * 1024)
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(kern, dim3(count), dim3(64 * TW), lds, b->eng->stream, w);
+  HIP_TRY(hipGetLastError());
+  return BIALIGN_OK;
+}
+
+template <int S>
+int launch_fill_linear(bialign_batch* b, const DeviceBatch& v, int first, int count) {
+  const TeamShape ts = team_shape(b, first, count);
+  b->last_team = ts.tw;
+  if (b->dense)
+    return ts.tw >= 2 ? launch_fill_linear_t<S, 2, true>(b, v, first, count)
+                      : launch_fill_linear_t<S, 1, true>(b, v, first, count);
+  switch (ts.tw) {
+    case 8: return launch_fill_linear_t<S, 8>(b, v, first, count);
+    case 4: return launch_fill_linear_t<S, 4>(b, v, first, count);
+    case 2: return launch_fill_linear_t<S, 2>(b, v, first, count);
+    default: return launch_fill_linear_t<S, 1>(b, v, first, count);
+  }
+}
+
+template <int S>
+int launch_traceback_linear(const bialign_batch* b, const DeviceBatch& v, int first, int count,
+                            bool do_trace) {
+  DeviceBatch w = v;
+  w.order = v.order + first;
+  const int blocks = count;  // one wave per pair
+  if (b->lds_trace > 64 * 1024)
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(traceback_linear_kernel<S, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_trace));
+  if (do_trace)
+    hipLaunchKernelGGL((traceback_linear_kernel<S, true>), dim3(blocks), dim3(64), b->lds_trace, b->eng->stream, w, count);
+  else
+    hipLaunchKernelGGL((traceback_linear_kernel<S, false>), dim3(blocks), dim3(64), 0, b->eng->stream, w, count);
+  HIP_TRY(hipGetLastError());
+  return BIALIGN_OK;
+}
+
+template <int S, int NL>
+int launch_dump(const bialign_batch* b, const DeviceBatch& v, int pid, int32_t* d_out) {
+  hipLaunchKernelGGL((dump_layers_kernel<S, NL>), dim3(256), dim3(256), 0, b->eng->stream, v, pid, d_out);
+  HIP_TRY(hipGetLastError());
+  return BIALIGN_OK;
+}
+
+// ---- instantiation plan: kind 0 = affine fill (the big kernels), kind 1 = everything else
+#define BIALIGN_INST_KIND0(S, X) X template int launch_fill_affine<S>(bialign_batch*, const DeviceBatch&, int, int);
+#define BIALIGN_INST_KIND1(S, X)                                                                         \
+  X template int launch_fill_linear<S>(bialign_batch*, const DeviceBatch&, int, int);                   \
+  X template int launch_traceback_affine<S>(const bialign_batch*, const DeviceBatch&, int, int, bool);  \
+  X template int launch_traceback_linear<S>(const bialign_batch*, const DeviceBatch&, int, int, bool);  \
+  X template int launch_dump<S, 9>(const bialign_batch*, const DeviceBatch&, int, int32_t*);            \
+  X template int launch_dump<S, 1>(const bialign_batch*, const DeviceBatch&, int, int32_t*);
+#define BIALIGN_FOR_EACH_S(M, X) M(0, X) M(1, X) M(2, X) M(3, X) M(4, X) M(5, X)
+
+#ifndef BIALIGN_TU_S  // every other unit: the instantiations live elsewhere
+BIALIGN_FOR_EACH_S(BIALIGN_INST_KIND0, extern)
+BIALIGN_FOR_EACH_S(BIALIGN_INST_KIND1, extern)
+#endif
+
+}  // namespace bialign

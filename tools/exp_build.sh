@@ -1,6 +1,11 @@
 #!/bin/bash
 # Timing-experiment builds of the engine (results are WRONG by construction; never shipped).
-# usage: tools/exp_build.sh <BIALIGN_EXP value> <output .so>
+# usage: tools/exp_build.sh <output .so> [DEFINE[=value] ...]     e.g.  tools/exp_build.sh /tmp/x.so BIALIGN_EXP=1
 set -e
 cd "$(dirname "$0")/.."
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -DBIALIGN_EXP=$1 -o "$2" bialign_amd/csrc/bialign_capi.hip
+out="$1"; shift
+python - "$out" "$@" <<'PY'
+import sys
+from bialign_amd.build import build
+print(build(force=True, out=sys.argv[1], defines=sys.argv[2:]))
+PY
