@@ -10,7 +10,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("BIALIGN_LIB_OVERRIDE") or os.path.join(HERE, "libbialign_hip.so")  # override: timing experiments only
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 RUN_FILL_ONLY = 1
 REC_AUTO, REC_AFFINE, REC_LINEAR = 0, 1, 2
 MAX_SHIFT = 5
@@ -58,6 +58,7 @@ SYMBOLS = [
     ("bialign_last_error", ctypes.c_char_p, []),
     ("bialign_engine_create", ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]),
     ("bialign_engine_destroy", None, [ctypes.c_void_p]),
+    ("bialign_engine_trim", ctypes.c_int, [ctypes.c_void_p]),
     ("bialign_batch_create", ctypes.c_int,
      [ctypes.c_void_p, ctypes.POINTER(Params), ctypes.POINTER(Scoring), ctypes.POINTER(Pairs),
       ctypes.c_int64, ctypes.POINTER(ctypes.c_void_p)]),

@@ -331,6 +331,7 @@ int bialign_batch_create(bialign_engine* eng, const bialign_params* prm, const b
   // ---- chunking under the HBM budget; inside a chunk longest sweeps first
   size_t free_b = 0, total_b = 0;
   HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+  free_b += eng->layer_cache.n * sizeof(int32_t);  // reused or released below, ours either way
   int64_t budget = hbm_budget > 0 ? hbm_budget : (int64_t)(free_b * 0.85);
   budget = std::min<int64_t>(budget, (int64_t)(free_b * 0.95));
   const int64_t budget_dw = budget / 4;
@@ -376,7 +377,13 @@ int bialign_batch_create(bialign_engine* eng, const bialign_params* prm, const b
   HIP_TRY(b->d_seq_b.upload(pr->seq_b, tot_b, st));
   HIP_TRY(b->d_cls_b.upload(b->dense ? zeros.data() : pr->cls_b, tot_b, st));
   if (b->dense) HIP_TRY(b->d_mu2.upload(pr->mu2_dense, (size_t)tot_mu2, st));
-  HIP_TRY(b->d_layers.alloc(b->max_chunk_dwords + 16));  // slack: ghost tail pieces are read 16 B wide
+  const size_t layer_dw = (size_t)b->max_chunk_dwords + 16;  // slack: ghost tail pieces are read 16 B wide
+  if (eng->layer_cache.p && eng->layer_cache.n >= layer_dw) {
+    b->d_layers.swap(eng->layer_cache);
+  } else {
+    eng->layer_cache.release();
+    HIP_TRY(b->d_layers.alloc(layer_dw));
+  }
   if (getenv("BIALIGN_DEBUG"))
     fprintf(stderr, "[bialign] layers %p (%.1f GiB)\n", (void*)b->d_layers.p, b->max_chunk_dwords * 4.0 / (1 << 30));
   HIP_TRY(b->d_scores.alloc(pr->npairs));
@@ -395,7 +402,19 @@ int bialign_batch_create(bialign_engine* eng, const bialign_params* prm, const b
 void bialign_batch_destroy(bialign_batch* b) {
   if (!b) return;
   (void)hipSetDevice(b->eng->device);
+  bialign_engine* eng = b->eng;
+  if (b->d_layers.p && b->d_layers.n > eng->layer_cache.n) {
+    (void)hipStreamSynchronize(eng->stream);
+    eng->layer_cache.swap(b->d_layers);  // keep the larger buffer for the next batch
+  }
   delete b;
+}
+
+int bialign_engine_trim(bialign_engine* e) {
+  if (!e) return fail(BIALIGN_E_INVALID, "NULL argument");
+  HIP_TRY(hipSetDevice(e->device));
+  e->layer_cache.release();
+  return BIALIGN_OK;
 }
 
 int bialign_batch_get_info(const bialign_batch* b, bialign_batch_info* info) {

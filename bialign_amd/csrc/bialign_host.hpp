@@ -40,6 +40,10 @@ struct DevBuf {
     p = nullptr;
     n = 0;
   }
+  void swap(DevBuf& o) {
+    std::swap(p, o.p);
+    std::swap(n, o.n);
+  }
   hipError_t alloc(size_t count) {
     release();
     n = count;
@@ -73,6 +77,10 @@ struct bialign_engine {
   int num_cu = 256;
   hipStream_t stream = nullptr;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  // Layer buffer kept between batches: hipMalloc / hipFree of tens of GB cost 0.1-6 s, the
+  // sweep itself ~20 ms.  A batch takes it at creation when it is large enough and hands
+  // the larger of (its own, the cached one) back at destruction; bialign_engine_trim frees it.
+  DevBuf<int32_t> layer_cache;
 };
 
 struct bialign_batch {

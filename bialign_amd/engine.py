@@ -4,6 +4,7 @@ Thin by design -- argument marshalling only.  All DP work happens in
 libbialign_hip.so on the GPU; nothing here computes alignments.
 """
 import ctypes
+import weakref
 
 import numpy as np
 
@@ -30,11 +31,18 @@ class Engine:
 
     def __init__(self, device=0):
         self._h = ctypes.c_void_p()
+        self._batches = weakref.WeakSet()  # live batches: closed before the engine goes away
         check(lib.bialign_engine_create(int(device), ctypes.byref(self._h)))
         self.device = int(device)
 
+    def trim(self):
+        """Release the layer buffer the engine keeps between batches (tens of GB after a large batch)."""
+        check(lib.bialign_engine_trim(self._h))
+
     def close(self):
         if getattr(self, "_h", None):
+            for batch in list(self._batches):
+                batch.close()
             lib.bialign_engine_destroy(self._h)
             self._h = None
 
@@ -109,6 +117,7 @@ class Batch:
         self._h = ctypes.c_void_p()
         check(lib.bialign_batch_create(engine._h, ctypes.byref(prm), ctypes.byref(sc), ctypes.byref(pr),
                                        int(hbm_budget_bytes), ctypes.byref(self._h)))
+        engine._batches.add(self)
         info = _lib.BatchInfo()
         check(lib.bialign_batch_get_info(self._h, ctypes.byref(info)))
         self.info = {k: getattr(info, k) for k, _ in info._fields_}

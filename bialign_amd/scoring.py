@@ -109,16 +109,38 @@ class ScoreModel:
         self.s2 = np.zeros((k2, k2), dtype=np.int32)
         np.fill_diagonal(self.s2, sw)  # pyx:425-428 / 416-423 with 0/1 features
 
+    def _encode(self, text, index):
+        """Letters -> uint8 codes through a 256-entry table (one numpy gather per molecule); the
+        first letter outside the alphabet raises KeyError like the reference's dict look-up."""
+        luts = self.__dict__.setdefault("_luts", {})
+        lut = luts.get(id(index))
+        if lut is None:
+            lut = False  # exotic alphabet: per-letter path below
+            if len(index) < 255 and all(len(c) == 1 and ord(c) < 256 for c in index):
+                lut = np.full(256, 255, dtype=np.uint8)
+                for c, x in index.items():
+                    lut[ord(c)] = x
+            luts[id(index)] = lut
+        if lut is not False:
+            try:
+                raw = np.frombuffer(text.encode("latin-1"), dtype=np.uint8)
+            except UnicodeEncodeError:
+                raw = None
+            if raw is not None:
+                codes = lut[raw]
+                if codes.size and codes.max() == 255:
+                    raise KeyError(text[int(np.argmax(codes == 255))])
+                return codes
+        return np.fromiter((index[c] for c in text), dtype=np.uint8, count=len(text))
+
     def encode_sequence(self, seq):
-        try:
-            return np.fromiter((self.seq_index[c] for c in seq), dtype=np.uint8, count=len(seq))
-        except KeyError as e:  # the reference raises KeyError at the first mu1 look-up (pyx:407)
-            raise KeyError(e.args[0]) from None
+        # an unknown residue raises KeyError as the reference does at its first mu1 look-up (pyx:407)
+        return self._encode(seq, self.seq_index)
 
     def encode_structure(self, structure):
         if self.is_rna:
             return rna_classes(structure)
-        return np.fromiter((self.cls_index[c] for c in structure), dtype=np.uint8, count=len(structure))
+        return self._encode(structure, self.cls_index)
 
     def mu1(self, code_a, code_b):
         return int(self.s1[code_a, code_b])

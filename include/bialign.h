@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define BIALIGN_ABI_VERSION 4
+#define BIALIGN_ABI_VERSION 5
 
 #define BIALIGN_OK 0
 #define BIALIGN_E_INVALID (-1)     /* bad argument (message says which) */
@@ -118,11 +118,15 @@ int bialign_abi_version(void);
 int bialign_device_count(void);
 const char* bialign_last_error(void);
 
-/* Engine: device selection + one HIP stream + event pool.
- * Replaces nothing in the reference (it has no device); one engine plays the
+/* Replaces nothing in the reference (it has no device); one engine plays the
  * role of the Python process that owns a BiAligner. */
+/* Engine: device selection + one HIP stream + event pool + the layer buffer of the last batch
+ * (kept for the next one: allocating tens of GB costs far more than sweeping them).  An engine
+ * and its batches are used from one thread at a time. */
 int bialign_engine_create(int device, bialign_engine** out);
 void bialign_engine_destroy(bialign_engine* eng);
+/* Give the cached layer buffer back to the device (e.g. before another library needs the HBM). */
+int bialign_engine_trim(bialign_engine* eng);
 
 /* Upload a batch and allocate its DP storage: BiAligner.__init__ (pyx:179-197)
  * for the part that reaches the DP, plus AffineDPMatrices / SparseMatrix4D

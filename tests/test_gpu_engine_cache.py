@@ -1,0 +1,55 @@
+"""The engine keeps the layer buffer of a finished batch for the next one (hipMalloc of tens of
+GB costs far more than the sweep).  Results must not depend on whose buffer a batch runs in."""
+import numpy as np
+import pytest
+
+from bialign_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def solve(engine, pairs, params):
+    from bialign_amd.batch import make_batch
+    b = make_batch(pairs, params, engine=engine)
+    b.run()
+    out = [int(v) for v in b.scores()], [t.tolist() for t in b.traces()[0]]
+    return b, out
+
+
+def test_buffer_reuse_across_batches_and_trim():
+    from oracle import oracle
+    from bialign_amd.engine import Engine
+    eng = Engine(0)
+    params = dict(synth.PROTEIN_PARAMS)
+    big = [synth.protein_pair(500 + t, 150, 140) for t in range(6)]
+    small = [synth.protein_pair(600 + t, 20 + t, 31) for t in range(3)]
+    want_big = [oracle.solve(*p, params)["score"] for p in big]
+    want_small = [oracle.solve(*p, params)["score"] for p in small]
+
+    b1, r1 = solve(eng, big, params)
+    assert r1[0] == want_big
+    b1.close()                                  # buffer goes to the engine
+    b2, r2 = solve(eng, small, params)          # runs inside the (larger, dirty) cached buffer
+    assert r2[0] == want_small
+    assert r2[1] == [oracle.solve(*p, params)["trace"].tolist() for p in small]
+    b3, r3 = solve(eng, big, params)            # cache is taken: allocates its own
+    assert r3 == r1
+    b2.close()
+    b3.close()
+    b4, r4 = solve(eng, big, dict(params, max_shift=2))   # larger than anything cached: reallocates
+    assert r4[0] == [oracle.solve(*p, dict(params, max_shift=2))["score"] for p in big]
+    b4.close()
+    eng.trim()
+    b5, r5 = solve(eng, small, params)          # after trim: fresh allocation
+    assert r5 == r2
+    b5.close()
+    eng.close()
+
+
+def test_engine_close_closes_its_batches():
+    from bialign_amd.engine import Engine
+    eng = Engine(0)
+    b, _ = solve(eng, [synth.protein_pair(1, 30, 30)], dict(synth.PROTEIN_PARAMS))
+    eng.close()
+    assert b._h is None
+    b.close()  # idempotent
