@@ -180,9 +180,26 @@ struct GhostFeed {
           : "memory");
     }
   }
-  // All DMAs of the previous block were issued >= BLK steps (>= 63 vector-memory
-  // operations) ago; vmcnt is in-order, so any counted wait below 64 retires them.
-  __device__ static __forceinline__ void wait_block() { asm volatile("s_waitcnt vmcnt(40)" ::: "memory"); }
+  // Store instructions a storing step issues at least (chunks + tail), i.e. vector-memory
+  // operations younger than the block's DMAs that each such step adds.
+  static constexpr int STORES_PER_STEP = R_::NCH4 + (R_::TAIL ? 1 : 0);
+
+  // Retire the DMAs of the block about to be consumed.  vmcnt retires in order, so waiting
+  // until at most N operations are outstanding retires everything older than the N youngest:
+  // the wait is correct iff MORE than N vector-memory operations were issued after the DMAs.
+  // `younger` is the wave's own count of those (the stores of the block's steps; idle steps
+  // and short records issue none), so the deepest wait it justifies is picked here -- the
+  // store queue is never drained further than needed, and never less.  Afterwards every
+  // store older than the block just finished is acknowledged too.
+  __device__ static __forceinline__ void wait_block(int younger) {
+    if (younger > 40) asm volatile("s_waitcnt vmcnt(40)" ::: "memory");
+    else if (younger > 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+    else if (younger > 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if (younger > 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if (younger > 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else if (younger > 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
 
   __device__ static __forceinline__ void fetch(int (&out)[R_::ND], const v4i* half, int t, int aa) {
     const v4i* src = half + (t * W + aa) * NP;
@@ -450,6 +467,7 @@ __global__ void __launch_bounds__(64 * TW) fill_affine_kernel(const DeviceBatch 
   // block 0 must be in the ring before the first step (waves w >= 1 start on a real ghost row)
   prefetch_block(0, 0, jj);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  int vm_younger = 0;  // store instructions issued since the last block's DMAs (wave-uniform)
 
   // One step of the sweep.  INTERIOR steps (every lane's lattice points have all
   // four coordinates >= 1 and lie inside the molecule columns; ~90 % of the
@@ -463,9 +481,11 @@ __global__ void __launch_bounds__(64 * TW) fill_affine_kernel(const DeviceBatch 
     //         (before this step's stores); then pick this step's ghost layers out of the ring
     const int gt = g & (GF::BLK - 1), ghalf = (g / GF::BLK) & 1;
     if (gt == 0) {
-      GF::wait_block();
-      if ((XCU || TW > 1) && L == 0) prog_put(g - 8);  // <= 40 vector-memory ops pending = < 6 steps of stores
+      GF::wait_block(vm_younger);
+      // all stores of steps before the block just finished are acknowledged (BLK <= 8)
+      if ((XCU || TW > 1) && L == 0) prog_put(g - 8);
       prefetch_block(g + GF::BLK, ghalf ^ 1, jj + GF::BLK);
+      vm_younger = 0;
     }
     GF::fetch(ghostM, ring + ghalf * GF::SLOTS, gt, aa);
 
@@ -520,6 +540,7 @@ __global__ void __launch_bounds__(64 * TW) fill_affine_kernel(const DeviceBatch 
                           (INTERIOR || __builtin_amdgcn_ballot_w64(tile_act && !ghost) != 0) &&
                           ((!XCU && TW == 1) || rec <= rec_last);
     const int slot = L - W;  // storage slot of a real lane
+    if (__builtin_amdgcn_ballot_w64(do_store) != 0) vm_younger += GF::STORES_PER_STEP;
     int32_t* const dst = BIALIGN_EXP == 2
                              ? A.layers + ((int64_t)(blockIdx.x & 255) << 18) + (int64_t)(g & 31) * RECDW
                              : lay + (int64_t)rec * RECDW;
@@ -986,13 +1007,15 @@ __global__ void __launch_bounds__(64 * TW) fill_linear_kernel(const DeviceBatch 
   };
   prefetch_block(0, 0, jj);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  int vm_younger = 0;  // see the affine kernel
 
   for (int g = 0; g < H; ++g) {
     const int gt = g & (GF::BLK - 1), ghalf = (g / GF::BLK) & 1;
     if (gt == 0) {
-      GF::wait_block();
+      GF::wait_block(vm_younger);
       if (T > 1 && L == 0) prog[w] = g - 8;
       prefetch_block(g + GF::BLK, ghalf ^ 1, jj + GF::BLK);
+      vm_younger = 0;
     }
     GF::fetch(ghostM, ring + ghalf * GF::SLOTS, gt, aa);
     int inLW[W], inLW1[W], inL1[W];
@@ -1061,8 +1084,10 @@ __global__ void __launch_bounds__(64 * TW) fill_linear_kernel(const DeviceBatch 
     }
 
     const int rec = g + rec_base;
-    if (__builtin_amdgcn_ballot_w64(tile_act && !ghost) != 0 && live && !ghost &&
-        (T == 1 || rec <= rec_last)) {  // see the affine kernel
+    const bool do_store = __builtin_amdgcn_ballot_w64(tile_act && !ghost) != 0 && live && !ghost &&
+                          (T == 1 || rec <= rec_last);  // see the affine kernel
+    if (__builtin_amdgcn_ballot_w64(do_store) != 0) vm_younger += GF::STORES_PER_STEP;
+    if (do_store) {
       const int slot = L - W;
       int32_t* dst = lay + (int64_t)rec * RECDW;
 #pragma unroll
