@@ -74,10 +74,15 @@ TeamShape team_shape(const bialign_batch* b, int first, int count) {
     const int wg_cu = (int)std::min<size_t>((160 * 1024) / lds, (size_t)(waves_cu_regs / t));
     return std::min<int64_t>((int64_t)count * t, (int64_t)b->eng->num_cu * wg_cu * t);
   };
+  // Two-wave workgroups of the s=2 affine kernel (256 registers, two such workgroups per CU) measured
+  // 20-35 % slower per pair than one- or four-wave ones at the same number of resident waves
+  // (tools/team_table.sh; not so at s=1 or s=3), so that sweep goes 1 -> 4.
+  const bool skip2 = b->affine && b->S == 2 && tw >= 4;
   int64_t best = 0;
-  for (int c = 1; c <= tw; c *= 2) best = std::max(best, concurrent(c));
+  for (int c = 1; c <= tw; c *= 2)
+    if (!(skip2 && c == 2)) best = std::max(best, concurrent(c));
   int t = 1;
-  while (t < tw && concurrent(t) * 100 < best * 95) t *= 2;
+  while (t < tw && concurrent(t) * 100 < best * 95) t *= (skip2 && t == 1) ? 4 : 2;
   ts.tw = t;
   // cross-CU: only when the chip would stay mostly empty and the team can be at least doubled
   if (count * t <= 512 && gw >= 2 * t) {

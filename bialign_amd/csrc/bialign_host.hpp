@@ -62,7 +62,7 @@ inline int ghost_blk(int S) {
   (void)S;
   return BIALIGN_BLK_OVERRIDE;
 #else
-  return S <= 2 ? 8 : 4;
+  return S <= 1 ? 8 : 4;
 #endif
 }
 

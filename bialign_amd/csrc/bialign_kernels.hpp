@@ -142,7 +142,7 @@ struct GhostFeed {
 #ifdef BIALIGN_BLK_OVERRIDE
   static constexpr int BLK = BIALIGN_BLK_OVERRIDE;
 #else
-  static constexpr int BLK = S <= 2 ? 8 : 4;  // steps per prefetch block
+  static constexpr int BLK = S <= 1 ? 8 : 4;  // steps per prefetch block (the ring is 2*BLK*W*NP*16 bytes of LDS)
 #endif
   static constexpr int NPIECE = BLK * W * NP;
   static constexpr int ROUNDS = (NPIECE + 63) / 64;
