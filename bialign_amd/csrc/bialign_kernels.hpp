@@ -38,7 +38,7 @@
 
 #ifndef BIALIGN_EXP
 // timing experiments only (tools/exp_build.sh; results are wrong by construction):
-// 1 = no layer stores, 2 = stores wrap inside 1 MiB per wave, 3 = never take the
+// 1 = no layer stores, 2 = stores wrap inside 1 MiB per wave, 9 = no team hand-off waits, 3 = never take the
 // interior step variant, 4 = always take it
 #define BIALIGN_EXP 0
 #endif
@@ -435,7 +435,7 @@ __global__ void __launch_bounds__(64 * TW) fill_affine_kernel(const DeviceBatch 
       prog_lds[w] = v;
   };
   auto wait_partner = [&](int h_last) __attribute__((always_inline)) {
-    if ((!XCU && TW == 1) || T == 1 || team_failed) return;
+    if ((!XCU && TW == 1) || T == 1 || team_failed || BIALIGN_EXP == 9) return;  // 9: timing experiment, no hand-off waits
     const int src = w == 0 ? T - 1 : w - 1;
     const int need = h_last + 2 * (R - 1) + 1 - (w == 0 ? P : 0);
     // bounded spin: a protocol bug must surface as an error, never as a hung GPU
