@@ -1,0 +1,24 @@
+"""Few long pairs (BASELINE config 4 shape): fill time over allocations.  AB_PAIRS x AB_LEN RNA, s=2."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bialign_amd import synth
+from bialign_amd.batch import make_batch
+from bialign_amd.engine import default_engine
+E = lambda k, d: int(os.environ.get(k, d))
+pairs = synth.rna_batch(E("AB_PAIRS", 64), E("AB_LEN", 2000))
+params = dict(synth.RNA_PARAMS, max_shift=E("AB_S", 2))
+for cycle in range(E("AB_CYCLES", 3)):
+    b = make_batch(pairs, params)
+    ts = []
+    for _ in range(3):
+        b.run(); ts.append(b.timing()["fill_ms"])
+    t = b.timing()
+    b_scores = b.scores()
+    print(f"cycle {cycle}: fill ms " + " ".join(f"{x:.2f}" for x in ts) +
+          f"   team {t['waves_per_pair']}{'x' if t['cross_cu'] else ''} chunks {b.info['nchunks']}  "
+          f"{b.info['cells'] * 36 / min(ts) / 1e9:.2f} TB/s", flush=True)
+    b.close()
+    default_engine().trim()
+    if cycle == 0:
+        import hashlib
+        print("   scores sha", hashlib.sha1(b_scores.tobytes()).hexdigest()[:12], flush=True)
