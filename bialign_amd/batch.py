@@ -5,6 +5,8 @@ engine is batch-first (a single pair is a batch of one).  ``make_batch`` turns
 molecule strings into the LOOKUP form the C ABI takes; ``shard`` splits a batch
 over the ranks of a one-process-per-GPU job.
 """
+import bisect
+
 from .scoring import ScoreModel
 
 
@@ -31,9 +33,46 @@ def make_batch(pairs, params, engine=None, hbm_budget_bytes=0, recurrence=0, mu2
                  mu2_dense=mu2_dense)
 
 
-def shard(npairs, rank, world_size):
-    """Contiguous block of pair indices owned by ``rank`` (pairs are independent,
-    so sharding needs no data-path collective)."""
-    base, extra = divmod(npairs, world_size)
-    start = rank * base + min(rank, extra)
-    return range(start, start + base + (1 if rank < extra else 0))
+def shard(npairs, rank, world_size, costs=None):
+    """Contiguous block of pair indices owned by ``rank`` (pairs are independent, so sharding
+    needs no data-path collective).  Without ``costs`` the blocks hold equal numbers of pairs;
+    with ``costs`` (one non-negative number per pair, e.g. lattice cells) block r ends where the
+    running cost first reaches (r+1)/world of the total -- every rank computes the same cuts."""
+    if costs is None:
+        base, extra = divmod(npairs, world_size)
+        start = rank * base + min(rank, extra)
+        return range(start, start + base + (1 if rank < extra else 0))
+    if len(costs) != npairs:
+        raise ValueError("costs needs one entry per pair")
+    return _cost_cuts(costs, world_size)[rank]
+
+
+def _cost_cuts(costs, world_size):
+    """world_size contiguous ranges; cut r sits where the running cost is nearest to
+    (r+1)/world of the total (integer arithmetic, ties to the earlier cut)."""
+    running = [0]
+    for c in costs:
+        if c < 0:
+            raise ValueError("costs must be non-negative")
+        running.append(running[-1] + int(c))
+    total, n = running[-1], len(costs)
+    cuts, start = [], 0
+    for r in range(world_size):
+        if r == world_size - 1:
+            stop = n
+        else:
+            target = total * (r + 1)                      # compare running[x] * world with it
+            stop = bisect.bisect_left(running, -(-target // world_size), lo=start)  # first reach
+            stop = min(stop, n)
+            if stop > start and 2 * target - (running[stop - 1] + running[stop]) * world_size <= 0:
+                stop -= 1                                 # the cut before is at least as near
+        cuts.append(range(start, stop))
+        start = stop
+    return cuts
+
+
+def pair_cost(pair, max_shift):
+    """Lattice cells of one (seqA, seqB, ...) pair: K(n,s) * K(m,s)."""
+    s = int(max_shift)
+    k = lambda x: (x + 1) * (2 * s + 1) - s * (s + 1)
+    return k(len(pair[0])) * k(len(pair[1]))

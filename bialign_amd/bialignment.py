@@ -104,6 +104,15 @@ _LINEAR_OFFSETS = ((1, 1, 1, 1), (1, 0, 1, 0), (0, 1, 0, 1), (1, 1, 0, 0), (0, 0
                    (1, 0, 1, 1), (0, 1, 1, 1), (1, 1, 1, 0), (1, 1, 0, 1))  # pyx:233-248
 
 
+def _sequential_row_sums(mat):
+    """Row sums accumulated strictly left to right (ufunc.accumulate), i.e. the doubles Python's
+    sum() produces on this interpreter; numpy's .sum() adds pairwise and rounds differently."""
+    mat = np.asarray(mat, dtype=float)
+    if mat.shape[1] == 0:
+        return np.zeros(mat.shape[0])
+    return np.add.accumulate(mat, axis=1)[:, -1]
+
+
 def _binary_features(mol):
     """True when up/down/unp hold only 0.0 / 1.0, i.e. come from a fixed structure string."""
     return all(v in (0.0, 1.0) for key in ("up", "down", "unp") for v in mol[key][1:])
@@ -125,8 +134,10 @@ class BiAligner:
 
     def __init__(self, seqA, seqB, strA, strB, **params):
         self._params = params
-        self.molA = self._preprocess_seq(seqA, strA)
-        self.molB = self._preprocess_seq(seqB, strB)
+        # bppA / bppB: optional externally computed base-pair probabilities (see _preprocess_seq)
+        bpp_a, bpp_b = params.get("bppA"), params.get("bppB")
+        self.molA = self._preprocess_seq(seqA, strA) if bpp_a is None else self._preprocess_seq(seqA, strA, bpp_a)
+        self.molB = self._preprocess_seq(seqB, strB) if bpp_b is None else self._preprocess_seq(seqB, strB, bpp_b)
         self.gamma = self._params["gap_cost"]
         self.beta = self._params["gap_opening_cost"]
         self.max_shift = self._params["max_shift"]
@@ -159,12 +170,11 @@ class BiAligner:
         """Upper-triangular pair probabilities -> symmetric matrix with unpaired
         probabilities on the diagonal; 1-based (pyx:326-338)."""
         n = len(bpp) - 1
-        sym = np.zeros((n + 1, n + 1), dtype="float")
-        for i in range(1, n + 1):
-            for j in range(i + 1, n + 1):
-                sym[i, j] = sym[j, i] = bpp[i][j]
-        for i in range(1, n + 1):
-            sym[i, i] = 1.0 - sum(sym[i, j] for j in range(1, n + 1))
+        upper = np.triu(np.asarray(bpp, dtype=float)[: n + 1, : n + 1], k=1)
+        upper[0, :] = 0.0
+        sym = upper + upper.T
+        # diagonal: 1.0 - (left-to-right sum of the row), the reference's Python sum() (pyx:335-336)
+        sym[np.arange(1, n + 1), np.arange(1, n + 1)] = 1.0 - _sequential_row_sums(sym[:, 1:])[1:]
         return sym
 
     @staticmethod
@@ -190,11 +200,24 @@ class BiAligner:
         dist = np.arange(n + 1)
         return [0] + [float(np.sum(sbpp[i, 1:] * (dist[1:] - i))) for i in range(1, n + 1)]
 
-    def _preprocess_seq(self, sequence, structure):
-        """pyx:340-376"""
+    def _preprocess_seq(self, sequence, structure, bpp=None):
+        """pyx:340-376.  ``bpp`` (extension): base-pair probabilities
+        computed elsewhere, in the layout of ViennaRNA's ``fold_compound.bpp()`` ((n+1) x (n+1),
+        1-based, upper triangle) -- the predicted-structure mode without the ViennaRNA dependency."""
         mol = {"seq": str(sequence)}
         mol["len"] = len(mol["seq"])
-        if structure is None:
+        if bpp is not None and self._is_rna:
+            if len(bpp) != mol["len"] + 1:
+                self.error("Provided base pair probabilities and sequence must have matching size.")
+            mol["sbpp"] = BiAligner._symmetrize_bpps(bpp)
+            mol["mea"] = mea(mol["sbpp"])
+            if structure is None:
+                structure = mol["mea"][0]
+            elif len(structure) != len(sequence):
+                self.error("Provided structure and sequence must have the same length.")
+            mol["structure"] = structure
+            mol["predicted"] = True
+        elif structure is None:
             if not self._is_rna:
                 self.error("Structures have to be provided when aligning proteins")
             import RNA  # ViennaRNA, exactly as the reference requires (pyx:347)
@@ -214,11 +237,13 @@ class BiAligner:
         if self._is_rna:
             # features, 1-based with an ignored entry 0 (pyx:366-374): "up" sums the
             # partners j <= i-2, "down" the partners j > i
-            n, sbpp = mol["len"], mol["sbpp"]
-            lower = np.tril(sbpp, k=-2)[:, 1:] if n else sbpp
-            upper = np.triu(sbpp, k=1)
-            mol["up"] = [float(v) for v in lower.sum(axis=1)]
-            mol["down"] = [float(v) for v in upper.sum(axis=1)]
+            # Sums run left to right like the reference's sum(): with real-valued probabilities
+            # the rounding order reaches mu2 through int() (pyx:416-423).
+            n, sbpp = mol["len"], np.asarray(mol["sbpp"], dtype=float)
+            col = np.arange(n + 1)
+            low = (col[None, :] >= 1) & (col[None, :] <= col[:, None] - 2)
+            mol["up"] = [float(v) for v in _sequential_row_sums(np.where(low, sbpp, 0.0))]
+            mol["down"] = [float(v) for v in _sequential_row_sums(np.where(col[None, :] > col[:, None], sbpp, 0.0))]
             mol["unp"] = [1.0 - u - d for u, d in zip(mol["up"], mol["down"])]
         return mol
 

@@ -30,10 +30,10 @@ def init_from_env(backend=None):
     return rank, local_rank, world
 
 
-def gather_scores(local_scores, npairs_total):
+def gather_scores(local_scores, npairs_total, costs=None):
     """All ranks -> the full int32 score vector in global pair order.
 
-    ``local_scores`` are this rank's scores for ``shard(npairs_total, rank, world)``.
+    ``local_scores`` are this rank's scores for ``shard(npairs_total, rank, world, costs)``.
     """
     import torch
     import torch.distributed as dist
@@ -42,36 +42,41 @@ def gather_scores(local_scores, npairs_total):
         assert len(local) == npairs_total
         return local.copy()
     world, rank = dist.get_world_size(), dist.get_rank()
-    assert len(local) == len(shard(npairs_total, rank, world))
-    width = -(-npairs_total // world)  # shards differ by at most one pair: pad to the widest
+    blocks = [shard(npairs_total, r, world, costs) for r in range(world)]
+    assert len(local) == len(blocks[rank])
+    width = max(1, max(len(b) for b in blocks))  # pad every shard to the widest
     dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
     mine = torch.zeros(width, dtype=torch.int32, device=dev)
     mine[:len(local)] = torch.from_numpy(local).to(dev)
     parts = [torch.empty_like(mine) for _ in range(world)]
     dist.all_gather(parts, mine)
     out = np.empty(npairs_total, dtype=np.int32)
-    for r, part in enumerate(parts):
-        blk = shard(npairs_total, r, world)
+    for blk, part in zip(blocks, parts):
         out[blk.start:blk.stop] = part[:len(blk)].cpu().numpy()
     return out
 
 
-def align_sharded(pairs, params, device=None, hbm_budget_bytes=0):
-    """Align this rank's shard of ``pairs`` on its GPU; every rank returns the
-    scores of ALL pairs (gathered) and the traces of its own shard."""
+def align_sharded(pairs, params, device=None, hbm_budget_bytes=0, balance=True):
+    """Align this rank's shard of ``pairs`` on its GPU; every rank returns the scores of ALL
+    pairs (gathered) and the traces of its own shard.  ``balance``: cut the shards by lattice
+    cells ("cost-balance by n*m when lengths vary") instead of pair count."""
     import torch.distributed as dist
-    from .batch import make_batch
-    from .engine import Engine
+    from .batch import make_batch, pair_cost
+    from .engine import default_engine
     world = dist.get_world_size() if dist.is_initialized() else 1
     rank = dist.get_rank() if dist.is_initialized() else 0
-    mine = shard(len(pairs), rank, world)
+    costs = [pair_cost(p, params["max_shift"]) for p in pairs] if balance else None
+    mine = shard(len(pairs), rank, world, costs)
     if device is None:
         import torch
         device = torch.cuda.current_device()
-    batch = make_batch([pairs[p] for p in mine], params, engine=Engine(device),
-                       hbm_budget_bytes=hbm_budget_bytes)
-    batch.run()
-    traces, complete = batch.traces()
-    scores = gather_scores(batch.scores(), len(pairs))
-    batch.close()
-    return scores, {p: (traces[t], bool(complete[t])) for t, p in enumerate(mine)}
+    local_scores, local = np.zeros(0, dtype=np.int32), {}
+    if len(mine):  # a rank may own nothing (fewer pairs than ranks, one giant pair)
+        batch = make_batch([pairs[p] for p in mine], params, engine=default_engine(device),
+                           hbm_budget_bytes=hbm_budget_bytes)
+        batch.run()
+        traces, complete = batch.traces()
+        local_scores = batch.scores()
+        local = {p: (traces[t], bool(complete[t])) for t, p in enumerate(mine)}
+        batch.close()
+    return gather_scores(local_scores, len(pairs), costs), local

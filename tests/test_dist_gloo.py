@@ -18,29 +18,34 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, npairs, q):
+def _worker(rank, world, port, npairs, q, balanced=False):
     sys.path.insert(0, REPO)
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     import torch.distributed as dist
     from bialign_amd import synth
-    from bialign_amd.batch import shard
+    from bialign_amd.batch import pair_cost, shard
     from bialign_amd.distributed import gather_scores, init_from_env
     from oracle import oracle
     r, _, w = init_from_env("gloo")
     assert (r, w) == (rank, world)
     params = dict(synth.PROTEIN_PARAMS)
     pairs = [synth.protein_pair(1000 + p, 12 + p % 5, 10 + p % 3) for p in range(npairs)]
-    mine = shard(npairs, rank, world)
+    if balanced:  # one pair far larger than the rest: shards of very different pair counts
+        pairs[0] = synth.protein_pair(999, 60, 50)
+    costs = [pair_cost(p, params["max_shift"]) for p in pairs] if balanced else None
+    mine = shard(npairs, rank, world, costs)
+    if balanced:
+        assert len(mine) == (1 if rank == 0 else npairs - 1)
     local = [oracle.solve(*pairs[p], params, want_trace=False)["score"] for p in mine]
-    allscores = gather_scores(np.array(local, dtype=np.int32), npairs)
+    allscores = gather_scores(np.array(local, dtype=np.int32), npairs, costs)
     dist.barrier()
     q.put((rank, allscores.tolist()))
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("npairs", [6, 7])
-def test_two_rank_score_gather(npairs):
+@pytest.mark.parametrize("npairs,balanced", [(6, False), (7, False), (7, True)])
+def test_two_rank_score_gather(npairs, balanced):
     import torch.multiprocessing as mp
     sys.path.insert(0, REPO)
     from bialign_amd import synth
@@ -48,7 +53,7 @@ def test_two_rank_score_gather(npairs):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, npairs, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, npairs, q, balanced)) for r in range(2)]
     for p in procs:
         p.start()
     got = dict(q.get(timeout=240) for _ in procs)
@@ -56,6 +61,8 @@ def test_two_rank_score_gather(npairs):
         p.join(timeout=60)
         assert p.exitcode == 0
     params = dict(synth.PROTEIN_PARAMS)
-    want = [oracle.solve(*synth.protein_pair(1000 + p, 12 + p % 5, 10 + p % 3), params, want_trace=False)["score"]
-            for p in range(npairs)]
+    pairs = [synth.protein_pair(1000 + p, 12 + p % 5, 10 + p % 3) for p in range(npairs)]
+    if balanced:
+        pairs[0] = synth.protein_pair(999, 60, 50)
+    want = [oracle.solve(*p, params, want_trace=False)["score"] for p in pairs]
     assert got[0] == want and got[1] == want

@@ -184,3 +184,34 @@ def test_dense_argument_errors():
     with pytest.raises(Exception) as e:
         make_batch([pair], dict(synth.PROTEIN_PARAMS), mu2_dense=[big])
     assert "safety window" in str(e.value)
+
+
+def test_bialigner_with_external_base_pair_probabilities():
+    """Predicted-structure mode without ViennaRNA: bppA / bppB in fold_compound.bpp() layout."""
+    import contextlib
+    import io
+    import math
+    from oracle import oracle
+    from bialign_amd import bialignment as ba
+    from test_host_mirror import random_bpp
+    sa, sb, _, _ = synth.rna_pair(77, 44, 39)
+    bpa, bpb = random_bpp(11, len(sa)), random_bpp(12, len(sb))
+    for ov in (dict(max_shift=1), dict(max_shift=2, gap_opening_cost=0, gap_cost=-200, shift_cost=-250)):
+        params = dict(synth.RNA_PARAMS, nameA="A", nameB="B", **ov)
+        b = ba.BiAligner(sa, sb, None, None, bppA=bpa, bppB=bpb, **params)
+        A, B, sw = b.molA, b.molB, params["structure_weight"]
+        n, m = len(sa), len(sb)
+        mu2 = np.zeros((n + 1, m + 1), dtype=np.int32)
+        for k in range(1, n + 1):
+            for l in range(1, m + 1):   # pyx:416-423, literally
+                mu2[k, l] = int(sw * (math.sqrt(A["up"][k] * B["up"][l]) + math.sqrt(A["down"][k] * B["down"][l])
+                                      + math.sqrt(A["unp"][k] * B["unp"][l])))
+        mu1, _ = oracle.mu_tables(sa, sb, "." * n, "." * m, params)
+        ref = oracle.solve_tables(n, m, params, mu1, mu2)
+        assert int(b.optimize()) == ref["score"]
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            trace = b.traceback()
+        assert [[int(v) for v in col] for col in trace] == oracle.trace_to_lists(ref["trace"])
+        lines = b.decode_trace(trace)
+        assert len(lines) >= 4 and all(isinstance(x, str) for x in lines)

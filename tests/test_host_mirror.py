@@ -207,3 +207,72 @@ def test_dense_mu2_negative_product_raises_like_math_sqrt():
     b = dict(up=[0, 0.2], down=[0, 0.2], unp=[0, 0.6])
     with pytest.raises(ValueError):
         scoring.dense_mu2_from_features(a, b, 400)
+
+
+# ---- base-pair probabilities -> features: same doubles as the reference's Python sums -----------
+def literal_symmetrize(bpp):
+    """pyx:326-338, word for word in plain Python."""
+    n = len(bpp) - 1
+    sb = np.zeros((n + 1, n + 1), dtype="float")
+    for i in range(1, n + 1):
+        for j in range(i + 1, n + 1):
+            sb[i, j] = bpp[i][j]
+            sb[j, i] = bpp[i][j]
+    for i in range(1, n + 1):
+        sb[i, i] = 1.0 - sum(sb[i, j] for j in range(1, n + 1))
+    return sb
+
+
+def literal_features(sbpp, n):
+    """pyx:366-374 in plain Python."""
+    up = [sum(sbpp[i][j] for j in range(1, i - 1)) for i in range(0, n + 1)]
+    down = [sum(sbpp[i][j] for j in range(i + 1, n + 1)) for i in range(0, n + 1)]
+    unp = [1.0 - up[i] - down[i] for i in range(0, n + 1)]
+    return up, down, unp
+
+
+def random_bpp(seed, n):
+    rng = np.random.default_rng(seed)
+    bpp = np.triu(rng.random((n + 1, n + 1)) ** 6, k=1)   # mostly tiny, a few sizeable entries
+    bpp[0, :] = 0.0
+    bpp *= 0.9 / max(1.0, (bpp + bpp.T).sum(axis=1).max())  # every row's pairing mass below 1
+    return bpp
+
+
+@pytest.mark.parametrize("seed,n", [(1, 1), (2, 2), (3, 3), (4, 17), (5, 60), (6, 131)])
+def test_bpp_to_features_bit_equal_to_literal_python(seed, n):
+    bpp = random_bpp(seed, n)
+    sym = ba.BiAligner._symmetrize_bpps(bpp)
+    want = literal_symmetrize(bpp)
+    assert sym.tobytes() == want.tobytes()
+    seq = "".join("ACGU"[(seed + t) % 4] for t in range(n))
+    b = ba.BiAligner(seq, seq, None, None, bppA=bpp, bppB=bpp, **dict(synth.RNA_PARAMS))
+    up, down, unp = literal_features(want, n)
+    for got, ref in ((b.molA["up"], up), (b.molA["down"], down), (b.molA["unp"], unp)):
+        assert np.array(got, dtype=float).tobytes() == np.array(ref, dtype=float).tobytes()
+    assert b.molA["predicted"] and len(b.molA["structure"]) == n
+
+
+def test_fixed_structure_features_unchanged_by_the_sequential_sums():
+    for rec in load_golden("small_layers.json"):
+        if rec["params"]["type"] != "RNA":
+            continue
+        b = ba.BiAligner(rec["seqA"], rec["seqB"], rec["strA"], rec["strB"], **rec["params"])
+        up, down, unp = oracle.rna_features(rec["strA"])
+        assert b.molA["up"] == up and b.molA["down"] == down and b.molA["unp"] == unp
+
+
+def test_cost_balanced_shards_partition_and_balance():
+    from bialign_amd.batch import pair_cost
+    rng = np.random.default_rng(3)
+    for world in (1, 2, 3, 8):
+        for trial in range(20):
+            costs = [int(c) for c in rng.integers(0, 1000, size=int(rng.integers(0, 40)))]
+            blocks = [shard(len(costs), r, world, costs) for r in range(world)]
+            assert [i for b in blocks for i in b] == list(range(len(costs)))       # ordered partition
+            loads = [sum(costs[i] for i in b) for b in blocks]
+            if costs:
+                assert max(loads) <= sum(costs) / world + max(costs)                # never worse than one pair off
+    assert pair_cost(("A" * 512, "C" * 512), 1) == 1537 * 1537                      # SURVEY.md 8d, config 2
+    with pytest.raises(ValueError):
+        shard(3, 0, 2, [1, 2])
