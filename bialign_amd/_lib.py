@@ -10,7 +10,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("BIALIGN_LIB_OVERRIDE") or os.path.join(HERE, "libbialign_hip.so")  # override: timing experiments only
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 RUN_FILL_ONLY = 1
 REC_AUTO, REC_AFFINE, REC_LINEAR = 0, 1, 2
 MAX_SHIFT = 5
@@ -25,7 +25,10 @@ c_u8p = ctypes.POINTER(ctypes.c_uint8)
 class Params(ctypes.Structure):
     _fields_ = [("gap_opening_cost", ctypes.c_int32), ("gap_cost", ctypes.c_int32),
                 ("shift_cost", ctypes.c_int32), ("max_shift", ctypes.c_int32),
-                ("recurrence", ctypes.c_int32)]
+                ("recurrence", ctypes.c_int32), ("flags", ctypes.c_uint32)]
+
+
+BATCH_SCORE_ONLY = 1  # BIALIGN_BATCH_SCORE_ONLY
 
 
 class Scoring(ctypes.Structure):

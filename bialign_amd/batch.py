@@ -24,13 +24,14 @@ def encode_pairs(pairs, params):
     return model, mols_a, mols_b
 
 
-def make_batch(pairs, params, engine=None, hbm_budget_bytes=0, recurrence=0, mu2_dense=None):
+def make_batch(pairs, params, engine=None, hbm_budget_bytes=0, recurrence=0, mu2_dense=None,
+               score_only=False):
     from .engine import Batch, default_engine  # loads the HIP library (no CPU fallback)
     model, mols_a, mols_b = encode_pairs(pairs, params)
     return Batch(engine or default_engine(), mols_a, mols_b, model.s1, model.s2,
                  params["gap_opening_cost"], params["gap_cost"], params["shift_cost"],
                  params["max_shift"], hbm_budget_bytes=hbm_budget_bytes, recurrence=recurrence,
-                 mu2_dense=mu2_dense)
+                 mu2_dense=mu2_dense, score_only=score_only)
 
 
 def shard(npairs, rank, world_size, costs=None):

@@ -41,6 +41,9 @@ def build_parser():
     for flags, kwargs in _OPTIONS:
         if flags[0] not in _PER_PAIR:
             p.add_argument(*flags, **kwargs)
+    p.add_argument("--score_only", action="store_true",
+                   help="Print one 'pair nameA nameB score' line per pair and skip the alignments "
+                        "(the GPU then keeps a fraction of the DP layers: faster, far less memory).")
     return p
 
 
@@ -65,26 +68,32 @@ def pair_block(idx, rec, params, score, trace, complete, verbose):
 
 def main(argv=None):
     args = build_parser().parse_args(argv)
-    params = {k: v for k, v in vars(args).items() if k not in ("pairs", "verbose")}
+    params = {k: v for k, v in vars(args).items() if k not in ("pairs", "verbose", "score_only")}
     records = read_pairs(args.pairs)
-    from .batch import make_batch, shard
+    from .batch import make_batch, pair_cost, shard
     from .distributed import gather_scores, init_from_env
-    from .engine import Engine, trace_codes_to_columns
+    from .engine import default_engine, trace_codes_to_columns
     rank, local_rank, world = init_from_env()
-    mine = shard(len(records), rank, world)
-    batch = make_batch([(r[1], r[4], r[2], r[5]) for r in (records[p] for p in mine)], params,
-                       engine=Engine(local_rank))
-    batch.run()
-    scores = batch.scores()
-    traces, complete = batch.traces()
-    affine = batch.affine
-    batch.close()
-    for t, p in enumerate(mine):
-        trace = trace_codes_to_columns(traces[t], as_tuples=not affine)
-        for line in pair_block(p, records[p], params, int(scores[t]), trace, bool(complete[t]), args.verbose):
-            print(line)
+    costs = [pair_cost((r[1], r[4]), params["max_shift"]) for r in records]  # shards balanced by lattice cells
+    mine = shard(len(records), rank, world, costs)
+    scores = []
+    if len(mine):
+        batch = make_batch([(r[1], r[4], r[2], r[5]) for r in (records[p] for p in mine)], params,
+                           engine=default_engine(local_rank), score_only=args.score_only)
+        batch.run()
+        scores = batch.scores()
+        if args.score_only:
+            for t, p in enumerate(mine):
+                print(f"pair {p}\t{records[p][0]}\t{records[p][3]}\t{int(scores[t])}")
+        else:
+            traces, complete = batch.traces()
+            for t, p in enumerate(mine):
+                trace = trace_codes_to_columns(traces[t], as_tuples=not batch.affine)
+                for line in pair_block(p, records[p], params, int(scores[t]), trace, bool(complete[t]), args.verbose):
+                    print(line)
+        batch.close()
     if world > 1:
-        allscores = gather_scores(scores, len(records))
+        allscores = gather_scores(scores, len(records), costs)
         if rank == 0:
             print("#scores\t" + "\t".join(str(int(s)) for s in allscores))
     return 0

@@ -278,6 +278,7 @@ int bialign_batch_create(bialign_engine* eng, const bialign_params* prm, const b
   b->k1 = sc->k1;
   b->k2 = sc->k2;
   b->dense = pr->mu2_dense != nullptr;
+  b->lean = (prm->flags & BIALIGN_BATCH_SCORE_ONLY) != 0;
   if (b->dense && !pr->mu2_off) return fail(BIALIGN_E_INVALID, "mu2_dense given without mu2_off");
   if (!b->dense && (!pr->cls_a || !pr->cls_b)) return fail(BIALIGN_E_INVALID, "cls_a / cls_b are NULL (LOOKUP form)");
   const int S = b->S, W = 2 * S + 1;
@@ -320,7 +321,8 @@ int bialign_batch_create(bialign_engine* eng, const bialign_params* prm, const b
     d.mu2_off = b->dense ? pr->mu2_off[p] : 0;
     if (b->dense) tot_mu2 = std::max<int64_t>(tot_mu2, pr->mu2_off[p] + (int64_t)n * m);
     b->trace_bytes += d.trace_cap;
-    pair_dwords[p] = (int64_t)d.G * ((64 / W - 1) * W) * b->NL * W;  // Rec<S,NL>::RECDW per step
+    pair_dwords[p] = b->lean ? (int64_t)d.G * ((W * b->NL * W + 3) / 4 * 4)      // Rec<S,NL,true>::RECDW per step
+                             : (int64_t)d.G * ((64 / W - 1) * W) * b->NL * W;  // Rec<S,NL>::RECDW
     b->cells += cells_of(n, m, S);
     tot_a = std::max<int64_t>(tot_a, pr->off_a[p] + n);
     tot_b = std::max<int64_t>(tot_b, pr->off_b[p] + m);
@@ -438,7 +440,7 @@ int bialign_batch_get_info(const bialign_batch* b, bialign_batch_info* info) {
 int bialign_batch_run(bialign_batch* b, uint32_t flags) {
   if (!b) return fail(BIALIGN_E_INVALID, "NULL batch");
   HIP_TRY(hipSetDevice(b->eng->device));
-  const bool do_trace = !(flags & BIALIGN_RUN_FILL_ONLY);
+  const bool do_trace = !(flags & BIALIGN_RUN_FILL_ONLY) && !b->lean;
   const DeviceBatch v = b->view();
   hipStream_t st = b->eng->stream;
   hipEvent_t* ev = b->eng->ev;
@@ -450,8 +452,10 @@ int bialign_batch_run(bialign_batch* b, uint32_t flags) {
     int rc = launch_fill(b, v, first, count);
     if (rc) return rc;
     HIP_TRY(hipEventRecord(ev[1], st));
-    rc = launch_traceback(b, v, first, count, do_trace);
-    if (rc) return rc;
+    if (!b->lean) {  // score-only batches: the sweep itself wrote the scores
+      rc = launch_traceback(b, v, first, count, do_trace);
+      if (rc) return rc;
+    }
     HIP_TRY(hipEventRecord(ev[2], st));
     HIP_TRY(hipEventSynchronize(ev[2]));
     float f = 0, t = 0;
@@ -489,6 +493,7 @@ int bialign_batch_get_scores(const bialign_batch* b, int32_t* scores) {
 int bialign_batch_get_traces(const bialign_batch* b, uint8_t* trace, int64_t* trace_off, int32_t* trace_len,
                              int32_t* complete) {
   if (!b || !trace || !trace_off || !trace_len || !complete) return fail(BIALIGN_E_INVALID, "NULL argument");
+  if (b->lean) return fail(BIALIGN_E_INVALID, "batch was created with BIALIGN_BATCH_SCORE_ONLY: it holds no layers to trace back");
   if (!b->ran || !b->ran_trace) return fail(BIALIGN_E_INVALID, "no traceback has been run on this batch");
   HIP_TRY(hipSetDevice(b->eng->device));
   HIP_TRY(hipMemcpy(trace, b->d_trace.p, b->trace_bytes, hipMemcpyDeviceToHost));
@@ -501,6 +506,7 @@ int bialign_batch_get_traces(const bialign_batch* b, uint8_t* trace, int64_t* tr
 int bialign_batch_dump_layers(bialign_batch* b, int32_t pair, int32_t* out) {
   if (!b || !out) return fail(BIALIGN_E_INVALID, "NULL argument");
   if (pair < 0 || pair >= b->npairs) return fail(BIALIGN_E_INVALID, "pair %d out of range", pair);
+  if (b->lean) return fail(BIALIGN_E_INVALID, "batch was created with BIALIGN_BATCH_SCORE_ONLY: it holds no layers");
   HIP_TRY(hipSetDevice(b->eng->device));
   hipStream_t st = b->eng->stream;
   // one-pair launch out of the regular launch order (team shape and layer offset are the pair's own)

@@ -101,6 +101,7 @@ struct bialign_batch {
   DevBuf<uint8_t> d_seq_a, d_cls_a, d_seq_b, d_cls_b, d_trace;
   DevBuf<int32_t> d_mu2;  // dense-mu2 mode: all pairs' n x m tables
   bool dense = false;
+  bool lean = false;  // score-only batch: LEAN records (bottom rows only), no traceback possible
   int k1 = 0, k2 = 0;
   bialign_timing timing{};
   bool ran = false, ran_trace = false;
@@ -134,12 +135,12 @@ struct TeamShape {
 
 TeamShape team_shape(const bialign_batch* b, int first, int count);
 
-template <int S, bool BETA_NONPOS, int TW, bool XCU, bool DENSE = false>
+template <int S, bool BETA_NONPOS, int TW, bool XCU, bool DENSE = false, bool LEAN = false>
 int launch_fill_affine_t(bialign_batch* b, const DeviceBatch& v, int first, int count, int gw) {
   DeviceBatch w = v;
   w.order = v.order + first;
   w.team = gw;
-  auto kern = fill_affine_kernel<S, BETA_NONPOS, TW, XCU, DENSE>;
+  auto kern = fill_affine_kernel<S, BETA_NONPOS, TW, XCU, DENSE, LEAN>;
   const size_t lds = b->lds_base + (size_t)TW * b->lds_per_wave;
   if (lds > 64 * 1024)
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -154,33 +155,38 @@ int launch_fill_affine_t(bialign_batch* b, const DeviceBatch& v, int first, int 
   return BIALIGN_OK;
 }
 
-template <int S>
-int launch_fill_affine(bialign_batch* b, const DeviceBatch& v, int first, int count) {
+template <int S, bool LEAN>
+int launch_fill_affine_l(bialign_batch* b, const DeviceBatch& v, int first, int count) {
   if (b->prm.gap_opening_cost > 0) {  // rare: general-beta algebra, one wave per pair
     b->last_team = 1;
-    return b->dense ? launch_fill_affine_t<S, false, 1, false, true>(b, v, first, count, 1)
-                    : launch_fill_affine_t<S, false, 1, false>(b, v, first, count, 1);
+    return b->dense ? launch_fill_affine_t<S, false, 1, false, true, LEAN>(b, v, first, count, 1)
+                    : launch_fill_affine_t<S, false, 1, false, false, LEAN>(b, v, first, count, 1);
   }
   const TeamShape ts = team_shape(b, first, count);
   b->last_team = ts.waves() * (ts.gw > 1 ? -1 : 1);
   if (b->dense) {
     if constexpr (S <= 3) {
-      if (ts.tw >= 2) return launch_fill_affine_t<S, true, 2, false, true>(b, v, first, count, 1);
+      if (ts.tw >= 2) return launch_fill_affine_t<S, true, 2, false, true, LEAN>(b, v, first, count, 1);
     }
     b->last_team = 1;
-    return launch_fill_affine_t<S, true, 1, false, true>(b, v, first, count, 1);
+    return launch_fill_affine_t<S, true, 1, false, true, LEAN>(b, v, first, count, 1);
   }
   if constexpr (S <= 3) {
-    if (ts.gw > 1) return launch_fill_affine_t<S, true, 1, true>(b, v, first, count, ts.gw);
+    if (ts.gw > 1) return launch_fill_affine_t<S, true, 1, true, false, LEAN>(b, v, first, count, ts.gw);
   }
   if constexpr (S <= 1) {
-    if (ts.tw == 8) return launch_fill_affine_t<S, true, 8, false>(b, v, first, count, 1);
+    if (ts.tw == 8) return launch_fill_affine_t<S, true, 8, false, false, LEAN>(b, v, first, count, 1);
   }
   if constexpr (S <= 3) {  // s >= 4 needs nearly all 512 registers of a SIMD lane: one wave per pair
-    if (ts.tw >= 4) return launch_fill_affine_t<S, true, 4, false>(b, v, first, count, 1);
-    if (ts.tw >= 2) return launch_fill_affine_t<S, true, 2, false>(b, v, first, count, 1);
+    if (ts.tw >= 4) return launch_fill_affine_t<S, true, 4, false, false, LEAN>(b, v, first, count, 1);
+    if (ts.tw >= 2) return launch_fill_affine_t<S, true, 2, false, false, LEAN>(b, v, first, count, 1);
   }
-  return launch_fill_affine_t<S, true, 1, false>(b, v, first, count, 1);
+  return launch_fill_affine_t<S, true, 1, false, false, LEAN>(b, v, first, count, 1);
+}
+
+template <int S>
+int launch_fill_affine(bialign_batch* b, const DeviceBatch& v, int first, int count) {
+  return b->lean ? launch_fill_affine_l<S, true>(b, v, first, count) : launch_fill_affine_l<S, false>(b, v, first, count);
 }
 
 template <int S>
@@ -200,11 +206,11 @@ int launch_traceback_affine(const bialign_batch* b, const DeviceBatch& v, int fi
   return BIALIGN_OK;
 }
 
-template <int S, int TW, bool DENSE = false>
+template <int S, int TW, bool DENSE = false, bool LEAN = false>
 int launch_fill_linear_t(bialign_batch* b, const DeviceBatch& v, int first, int count) {
   DeviceBatch w = v;
   w.order = v.order + first;
-  auto kern = fill_linear_kernel<S, TW, DENSE>;
+  auto kern = fill_linear_kernel<S, TW, DENSE, LEAN>;
   const size_t lds = b->lds_base + (size_t)TW * b->lds_per_wave;
   if (lds > 64 * 1024)
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -214,19 +220,24 @@ int launch_fill_linear_t(bialign_batch* b, const DeviceBatch& v, int first, int 
   return BIALIGN_OK;
 }
 
-template <int S>
-int launch_fill_linear(bialign_batch* b, const DeviceBatch& v, int first, int count) {
+template <int S, bool LEAN>
+int launch_fill_linear_l(bialign_batch* b, const DeviceBatch& v, int first, int count) {
   const TeamShape ts = team_shape(b, first, count);
   b->last_team = ts.tw;
   if (b->dense)
-    return ts.tw >= 2 ? launch_fill_linear_t<S, 2, true>(b, v, first, count)
-                      : launch_fill_linear_t<S, 1, true>(b, v, first, count);
+    return ts.tw >= 2 ? launch_fill_linear_t<S, 2, true, LEAN>(b, v, first, count)
+                      : launch_fill_linear_t<S, 1, true, LEAN>(b, v, first, count);
   switch (ts.tw) {
-    case 8: return launch_fill_linear_t<S, 8>(b, v, first, count);
-    case 4: return launch_fill_linear_t<S, 4>(b, v, first, count);
-    case 2: return launch_fill_linear_t<S, 2>(b, v, first, count);
-    default: return launch_fill_linear_t<S, 1>(b, v, first, count);
+    case 8: return launch_fill_linear_t<S, 8, false, LEAN>(b, v, first, count);
+    case 4: return launch_fill_linear_t<S, 4, false, LEAN>(b, v, first, count);
+    case 2: return launch_fill_linear_t<S, 2, false, LEAN>(b, v, first, count);
+    default: return launch_fill_linear_t<S, 1, false, LEAN>(b, v, first, count);
   }
+}
+
+template <int S>
+int launch_fill_linear(bialign_batch* b, const DeviceBatch& v, int first, int count) {
+  return b->lean ? launch_fill_linear_l<S, true>(b, v, first, count) : launch_fill_linear_l<S, false>(b, v, first, count);
 }
 
 template <int S>

@@ -94,15 +94,17 @@ struct Geo {
 // [slot][TAIL] tail, everything packed: a wave-wide store instruction writes one contiguous
 // run of SL*16 bytes and consecutive instructions / steps continue where the last one ended,
 // so every byte of a pair's region is written and L2 assembles full lines.
-template <int S, int NL>
+//   LEAN records (score-only batches): nobody will trace back, so a step keeps only what the
+// next strip's ghost row replays -- the bottom real row, W slots -- in the same chunk layout.
+template <int S, int NL, bool LEAN = false>
 struct Rec {
   static constexpr int W = 2 * S + 1;
-  static constexpr int SL = (64 / W - 1) * W;  // storage slots = real lanes
+  static constexpr int SL = LEAN ? W : (64 / W - 1) * W;  // storage slots = real lanes (bottom row only if LEAN)
   static constexpr int ND = NL * W;
   static constexpr int NCH4 = ND / 4;
   static constexpr int TAIL = ND % 4;
   static constexpr int CH = SL * 4;            // dwords per chunk
-  static constexpr int RECDW = SL * ND;
+  static constexpr int RECDW = LEAN ? (SL * ND + 3) / 4 * 4 : SL * ND;  // 16-byte pieces stay aligned
   __host__ __device__ static inline int64_t dword(int64_t g, int slot, int d) {
     return d < 4 * NCH4 ? g * RECDW + (d >> 2) * CH + slot * 4 + (d & 3)
                         : g * RECDW + NCH4 * CH + slot * TAIL + (d - 4 * NCH4);
@@ -134,9 +136,9 @@ __host__ __device__ inline int64_t cell_dword(const PairDesc& pd, int i, int j, 
 // one counted wait per block is written by hand.  The ghost of step g replays
 // record g - GOFF for every ghost lane alike, so the feed needs no lane state.
 // ---------------------------------------------------------------------------
-template <int S, int NL>
+template <int S, int NL, bool LEAN = false>
 struct GhostFeed {
-  using R_ = Rec<S, NL>;
+  using R_ = Rec<S, NL, LEAN>;
   static constexpr int W = 2 * S + 1, R = 64 / W;
   static constexpr int NP = R_::NCH4 + (R_::TAIL ? 1 : 0);  // 16-byte pieces per (step, a)
 #ifdef BIALIGN_BLK_OVERRIDE
@@ -166,7 +168,7 @@ struct GhostFeed {
       const int xr = blk_rem + t - aa;
       const int ql = blk_q + (xr >= P ? 1 : 0) - (xr < 0 ? 1 : 0);
       const int rec = min(max(h0 + t - GOFF + (ql * (T - 1) + w) * P, 0), rec_last);
-      const int sl = (R - 2) * W + aa;  // storage slot of the bottom real row
+      const int sl = LEAN ? aa : (R - 2) * W + aa;  // storage slot of the bottom real row
       const int32_t* p = lay + (int64_t)rec * R_::RECDW +
                          (c < R_::NCH4 ? c * R_::CH + sl * 4 : R_::NCH4 * R_::CH + sl * R_::TAIL);
       const uint32_t dst = lds_base + r * 1024;  // wave-uniform; lane l lands at dst + 16*l
@@ -313,11 +315,11 @@ __device__ __forceinline__ void store_chunk(int32_t* p, v4i v) {
     *reinterpret_cast<v4i*>(p) = v;
 }
 
-template <int S, bool BETA_NONPOS, int TW, bool XCU, bool DENSE = false>
+template <int S, bool BETA_NONPOS, int TW, bool XCU, bool DENSE = false, bool LEAN = false>
 __global__ void __launch_bounds__(64 * TW) fill_affine_kernel(const DeviceBatch A) {
   static_assert(!XCU || TW == 1, "cross-CU teams are built from one-wave workgroups");
   using G_ = Geo<S>;
-  using R_ = Rec<S, 9>;
+  using R_ = Rec<S, 9, LEAN>;
   constexpr int W = G_::W, R = G_::R, RR = G_::RR, PADB = G_::PADB;
   constexpr int XR = 12;  // exchange rows per point that go through LDS
   constexpr int NV = XR * W, ND = R_::ND, NCH4 = R_::NCH4, TAIL = R_::TAIL, RECDW = R_::RECDW;
@@ -325,7 +327,8 @@ __global__ void __launch_bounds__(64 * TW) fill_affine_kernel(const DeviceBatch 
 
   const int T = XCU ? A.team : TW;                       // team size
   const int slot = XCU ? blockIdx.x / T : blockIdx.x;     // pair of this launch
-  const PairDesc pd = A.pairs[A.order[slot]];
+  const int pid = A.order[slot];
+  const PairDesc pd = A.pairs[pid];
   const int n = pd.n, m = pd.m, P = pd.P;
   const int L = threadIdx.x & 63;
   const int wl = TW == 1 ? 0 : __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave in workgroup
@@ -339,7 +342,7 @@ __global__ void __launch_bounds__(64 * TW) fill_affine_kernel(const DeviceBatch 
 
   // ---- LDS carve-up: per wave a ghost ring and an exchange array; shared: progress
   //      words, score tables, sequence codes
-  using GF = GhostFeed<S, 9>;
+  using GF = GhostFeed<S, 9, LEAN>;
   using MF = Mu2Feed<S>;
   constexpr int PERW = GF::RING_DW + NV * NCOL + (DENSE ? MF::RING_DW : 0);  // dwords per wave
   v4i* ring = reinterpret_cast<v4i*>(smem + wl * GF::RING_DW);   // ghost-row ring, two halves
@@ -536,10 +539,10 @@ __global__ void __launch_bounds__(64 * TW) fill_affine_kernel(const DeviceBatch 
     // the store.  Each chunk is issued as soon as its four values exist, spreading the
     // stores over the step.
     const int rec = g + rec_base;  // lanes of two strips (straddling steps) hit two records
-    const bool do_store = BIALIGN_EXP != 1 && live && !ghost &&
+    const bool do_store = BIALIGN_EXP != 1 && live && (LEAN ? il == R - 1 : !ghost) &&
                           (INTERIOR || __builtin_amdgcn_ballot_w64(tile_act && !ghost) != 0) &&
                           ((!XCU && TW == 1) || rec <= rec_last);
-    const int slot = L - W;  // storage slot of a real lane
+    const int slot = LEAN ? aa : L - W;  // storage slot of a real lane
     if (__builtin_amdgcn_ballot_w64(do_store) != 0) vm_younger += GF::STORES_PER_STEP;
     int32_t* const dst = BIALIGN_EXP == 2
                              ? A.layers + ((int64_t)(blockIdx.x & 255) << 18) + (int64_t)(g & 31) * RECDW
@@ -624,6 +627,14 @@ __global__ void __launch_bounds__(64 * TW) fill_affine_kernel(const DeviceBatch 
       }
 #pragma unroll
       for (int q = 0; q < 9; ++q) outv[bb * 9 + q] = M[q];
+      if (LEAN && bb == S) {  // score-only: the end cell (n,m,n,m) is all the host wants (pyx:509)
+        if (live && !ghost && aa == S && i == n && jj == m) {
+          int best = M[0];
+#pragma unroll
+          for (int q = 1; q < 9; ++q) best = imax(best, M[q]);
+          A.scores[pid] = best;
+        }
+      }
       if (do_store) {
 #pragma unroll
         for (int c = 0; c < NCH4; ++c) {
@@ -891,16 +902,17 @@ __global__ void __launch_bounds__(64) traceback_affine_kernel(const DeviceBatch 
 // later and kept in registers for the cases that need them 2 or 3 steps later
 // (age of offset o = o0 + o1 + o2).
 // ---------------------------------------------------------------------------
-template <int S, int TW, bool DENSE = false>
+template <int S, int TW, bool DENSE = false, bool LEAN = false>
 __global__ void __launch_bounds__(64 * TW) fill_linear_kernel(const DeviceBatch A) {
   using G_ = Geo<S>;
-  using R_ = Rec<S, 1>;
+  using R_ = Rec<S, 1, LEAN>;
   constexpr int W = G_::W, R = G_::R, RR = G_::RR, PADB = G_::PADB;
   constexpr int NV = W, ND = R_::ND, NCH4 = R_::NCH4, TAIL = R_::TAIL, RECDW = R_::RECDW;
   extern __shared__ __align__(16) int32_t smem[];
 
   constexpr int T = TW;  // team = the workgroup's waves (see fill_affine_kernel)
-  const PairDesc pd = A.pairs[A.order[blockIdx.x]];
+  const int pid = A.order[blockIdx.x];
+  const PairDesc pd = A.pairs[pid];
   const int n = pd.n, m = pd.m, P = pd.P;
   const int L = threadIdx.x & 63;
   const int w = TW == 1 ? 0 : __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -911,7 +923,7 @@ __global__ void __launch_bounds__(64 * TW) fill_linear_kernel(const DeviceBatch 
   const int k1 = A.k1, k2 = A.k2;
   const int gD = gamma + delta, gg = 2 * gamma;
 
-  using GF = GhostFeed<S, 1>;
+  using GF = GhostFeed<S, 1, LEAN>;
   using MF = Mu2Feed<S>;
   constexpr int PERW = GF::RING_DW + NV * NCOL + (DENSE ? MF::RING_DW : 0);
   v4i* ring = reinterpret_cast<v4i*>(smem + w * GF::RING_DW);
@@ -1084,11 +1096,12 @@ __global__ void __launch_bounds__(64 * TW) fill_linear_kernel(const DeviceBatch 
     }
 
     const int rec = g + rec_base;
-    const bool do_store = __builtin_amdgcn_ballot_w64(tile_act && !ghost) != 0 && live && !ghost &&
-                          (T == 1 || rec <= rec_last);  // see the affine kernel
+    if (LEAN && live && !ghost && aa == S && i == n && jj == m) A.scores[pid] = outv[S];  // pyx:471
+    const bool do_store = __builtin_amdgcn_ballot_w64(tile_act && !ghost) != 0 && live &&
+                          (LEAN ? il == R - 1 : !ghost) && (T == 1 || rec <= rec_last);  // see the affine kernel
     if (__builtin_amdgcn_ballot_w64(do_store) != 0) vm_younger += GF::STORES_PER_STEP;
     if (do_store) {
-      const int slot = L - W;
+      const int slot = LEAN ? aa : L - W;
       int32_t* dst = lay + (int64_t)rec * RECDW;
 #pragma unroll
       for (int c = 0; c < NCH4; ++c) {

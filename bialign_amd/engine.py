@@ -66,10 +66,12 @@ class Batch:
     ``s1`` / ``s2``: int32 score tables (k1 x k1, k2 x k2).
     ``mu2_dense``: optional list of int32 arrays, pair p's of shape (n_p, m_p) with entry
     [k-1, l-1] = mu2(k, l); replaces the class codes / ``s2`` (DENSE form of include/bialign.h).
+    ``score_only``: the batch will never be traced back (BIALIGN_BATCH_SCORE_ONLY): the sweep keeps
+    only the rows the next strip needs; ``traces()`` / ``dump_layers()`` raise.
     """
 
     def __init__(self, engine, mols_a, mols_b, s1, s2, gap_opening_cost, gap_cost, shift_cost,
-                 max_shift, hbm_budget_bytes=0, recurrence=0, mu2_dense=None):
+                 max_shift, hbm_budget_bytes=0, recurrence=0, mu2_dense=None, score_only=False):
         if len(mols_a) != len(mols_b) or not mols_a:
             raise ValueError("need the same, non-zero number of A and B molecules")
         self.engine = engine
@@ -108,7 +110,7 @@ class Batch:
             mu2_flat = np.ascontiguousarray(np.concatenate(flat))
             mu2_ptr, mu2_off_ptr = _ptr(mu2_flat, ctypes.c_int32), _ptr(mu2_off, ctypes.c_int64)
         prm = _lib.Params(int(gap_opening_cost), int(gap_cost), int(shift_cost), int(max_shift),
-                          int(recurrence))
+                          int(recurrence), _lib.BATCH_SCORE_ONLY if score_only else 0)
         sc = _lib.Scoring(s1.shape[0], _ptr(s1, ctypes.c_int32), s2.shape[0], _ptr(s2, ctypes.c_int32))
         pr = _lib.Pairs(self.npairs, _ptr(self.len_a, ctypes.c_int32), _ptr(self.len_b, ctypes.c_int32),
                         _ptr(off_a, ctypes.c_int64), _ptr(off_b, ctypes.c_int64),

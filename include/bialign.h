@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define BIALIGN_ABI_VERSION 5
+#define BIALIGN_ABI_VERSION 6
 
 #define BIALIGN_OK 0
 #define BIALIGN_E_INVALID (-1)     /* bad argument (message says which) */
@@ -51,6 +51,12 @@ extern "C" {
 /* run flags */
 #define BIALIGN_RUN_FILL_ONLY 1u /* optimize() without traceback() */
 
+/* bialign_params.flags.  SCORE_ONLY: the batch will only ever be asked for scores (optimize()
+ * without a later traceback(), e.g. all-against-all scoring): the sweep keeps just the rows the
+ * next strip needs instead of all layers -- 1/20 of the HBM footprint and traffic at max_shift 1 --
+ * and bialign_batch_get_traces / bialign_batch_dump_layers fail with BIALIGN_E_INVALID. */
+#define BIALIGN_BATCH_SCORE_ONLY 1u
+
 typedef struct bialign_engine bialign_engine; /* one per (process, device) */
 typedef struct bialign_batch bialign_batch;   /* inputs resident in HBM */
 
@@ -63,6 +69,7 @@ typedef struct bialign_params {
   int32_t recurrence;       /* BIALIGN_REC_AUTO: affine iff gap_opening_cost != 0, as optimize()
                                dispatches (pyx:444); BIALIGN_REC_AFFINE = affine_optimize() called
                                directly (pyx:474); BIALIGN_REC_LINEAR = the 13-case recurrence */
+  uint32_t flags;           /* BIALIGN_BATCH_* */
 } bialign_params;
 
 /* Score tables, row-major, values already scaled (nonpyx:33: x100). */

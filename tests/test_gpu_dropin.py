@@ -180,6 +180,14 @@ def test_batch_cli_equals_single_pair_cli(tmp_path, capsys):
         head, body = blocks[t].split("\n", 1)
         assert head == f"{t}\t{na}\t{nb}"
         assert body == single
+    # --score_only: one line per pair with the same score, no alignment
+    batch_cli.main([str(f)] + opts + ["--score_only"])
+    lines = capsys.readouterr().out.strip().split("\n")
+    assert len(lines) == 4
+    for t, line in enumerate(lines):
+        cols = line.split("\t")
+        assert cols[:3] == [f"pair {t}", rows[t][0], rows[t][3]]
+        assert ("SCORE: " + cols[3]) in blocks[t]
 
 
 def test_c_abi_error_paths():
