@@ -10,7 +10,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("BIALIGN_LIB_OVERRIDE") or os.path.join(HERE, "libbialign_hip.so")  # override: timing experiments only
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 RUN_FILL_ONLY = 1
 REC_AUTO, REC_AFFINE, REC_LINEAR = 0, 1, 2
 MAX_SHIFT = 5
@@ -29,6 +29,7 @@ class Params(ctypes.Structure):
 
 
 BATCH_SCORE_ONLY = 1  # BIALIGN_BATCH_SCORE_ONLY
+BATCH_LEAN_TRACE = 2  # BIALIGN_BATCH_LEAN_TRACE
 
 
 class Scoring(ctypes.Structure):
@@ -45,7 +46,8 @@ class BatchInfo(ctypes.Structure):
     _fields_ = [("npairs", ctypes.c_int32), ("nchunks", ctypes.c_int32),
                 ("affine", ctypes.c_int32), ("max_shift", ctypes.c_int32),
                 ("cells", ctypes.c_int64), ("layer_bytes", ctypes.c_int64),
-                ("hbm_layer_bytes", ctypes.c_int64), ("trace_bytes", ctypes.c_int64)]
+                ("hbm_layer_bytes", ctypes.c_int64), ("trace_bytes", ctypes.c_int64),
+                ("storage", ctypes.c_int32), ("reserved", ctypes.c_int32)]
 
 
 class Timing(ctypes.Structure):

@@ -25,13 +25,13 @@ def encode_pairs(pairs, params):
 
 
 def make_batch(pairs, params, engine=None, hbm_budget_bytes=0, recurrence=0, mu2_dense=None,
-               score_only=False):
+               score_only=False, lean_trace=False):
     from .engine import Batch, default_engine  # loads the HIP library (no CPU fallback)
     model, mols_a, mols_b = encode_pairs(pairs, params)
     return Batch(engine or default_engine(), mols_a, mols_b, model.s1, model.s2,
                  params["gap_opening_cost"], params["gap_cost"], params["shift_cost"],
                  params["max_shift"], hbm_budget_bytes=hbm_budget_bytes, recurrence=recurrence,
-                 mu2_dense=mu2_dense, score_only=score_only)
+                 mu2_dense=mu2_dense, score_only=score_only, lean_trace=lean_trace)
 
 
 def shard(npairs, rank, world_size, costs=None):

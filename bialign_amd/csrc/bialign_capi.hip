@@ -150,6 +150,36 @@ int launch_fill(bialign_batch* b, const DeviceBatch& v, int first, int count) {
   return fail(BIALIGN_E_UNSUPPORTED, "no fill kernel for affine=%d max_shift=%d", b->affine, b->S);
 }
 
+// Lean traceback of one chunk: as many (re-sweep, walk) rounds as its longest pair has strips.
+int lean_traceback_rounds(bialign_batch* b, const DeviceBatch& v, int first, int count) {
+  hipStream_t st = b->eng->stream;
+  HIP_TRY(hipMemsetAsync(b->d_tstate.p, 0, sizeof(TraceState) * b->npairs, st));
+  int rounds = 0;
+  for (int t = first; t < first + count; ++t) rounds = std::max(rounds, b->pairs[b->order[t]].NS);
+  for (int r = 0; r < rounds; ++r) {
+    int rc = BIALIGN_E_UNSUPPORTED;
+    switch (b->S) {
+      case 0: rc = launch_resweep_affine<0>(b, v, first, count); break;
+      case 1: rc = launch_resweep_affine<1>(b, v, first, count); break;
+      case 2: rc = launch_resweep_affine<2>(b, v, first, count); break;
+      case 3: rc = launch_resweep_affine<3>(b, v, first, count); break;
+      case 4: rc = launch_resweep_affine<4>(b, v, first, count); break;
+      case 5: rc = launch_resweep_affine<5>(b, v, first, count); break;
+    }
+    if (rc) return rc;
+    switch (b->S) {
+      case 0: rc = launch_traceback_affine_strip<0>(b, v, first, count); break;
+      case 1: rc = launch_traceback_affine_strip<1>(b, v, first, count); break;
+      case 2: rc = launch_traceback_affine_strip<2>(b, v, first, count); break;
+      case 3: rc = launch_traceback_affine_strip<3>(b, v, first, count); break;
+      case 4: rc = launch_traceback_affine_strip<4>(b, v, first, count); break;
+      case 5: rc = launch_traceback_affine_strip<5>(b, v, first, count); break;
+    }
+    if (rc) return rc;
+  }
+  return BIALIGN_OK;
+}
+
 int launch_traceback(const bialign_batch* b, const DeviceBatch& v, int first, int count, bool do_trace) {
   if (b->affine) {
     switch (b->S) {
@@ -278,7 +308,10 @@ int bialign_batch_create(bialign_engine* eng, const bialign_params* prm, const b
   b->k1 = sc->k1;
   b->k2 = sc->k2;
   b->dense = pr->mu2_dense != nullptr;
-  b->lean = (prm->flags & BIALIGN_BATCH_SCORE_ONLY) != 0;
+  b->lean_trace = (prm->flags & BIALIGN_BATCH_LEAN_TRACE) != 0;
+  b->lean = b->lean_trace || (prm->flags & BIALIGN_BATCH_SCORE_ONLY) != 0;
+  if (b->lean_trace && (!b->affine || b->dense))
+    return fail(BIALIGN_E_UNSUPPORTED, "BIALIGN_BATCH_LEAN_TRACE needs the affine recurrence in LOOKUP form");
   if (b->dense && !pr->mu2_off) return fail(BIALIGN_E_INVALID, "mu2_dense given without mu2_off");
   if (!b->dense && (!pr->cls_a || !pr->cls_b)) return fail(BIALIGN_E_INVALID, "cls_a / cls_b are NULL (LOOKUP form)");
   const int S = b->S, W = 2 * S + 1;
@@ -321,8 +354,6 @@ int bialign_batch_create(bialign_engine* eng, const bialign_params* prm, const b
     d.mu2_off = b->dense ? pr->mu2_off[p] : 0;
     if (b->dense) tot_mu2 = std::max<int64_t>(tot_mu2, pr->mu2_off[p] + (int64_t)n * m);
     b->trace_bytes += d.trace_cap;
-    pair_dwords[p] = b->lean ? (int64_t)d.G * ((W * b->NL * W + 3) / 4 * 4)      // Rec<S,NL,true>::RECDW per step
-                             : (int64_t)d.G * ((64 / W - 1) * W) * b->NL * W;  // Rec<S,NL>::RECDW
     b->cells += cells_of(n, m, S);
     tot_a = std::max<int64_t>(tot_a, pr->off_a[p] + n);
     tot_b = std::max<int64_t>(tot_b, pr->off_b[p] + m);
@@ -342,6 +373,25 @@ int bialign_batch_create(bialign_engine* eng, const bialign_params* prm, const b
   int64_t budget = hbm_budget > 0 ? hbm_budget : (int64_t)(free_b * 0.85);
   budget = std::min<int64_t>(budget, (int64_t)(free_b * 0.95));
   const int64_t budget_dw = budget / 4;
+  // layer storage per pair in the batch's mode (dwords); a pair's scratch records follow its LEAN records
+  auto size_pairs = [&]() {
+    for (int p = 0; p < pr->npairs; ++p) {
+      PairDesc& d = b->pairs[p];
+      const int64_t full_rec = (int64_t)((64 / W - 1) * W) * b->NL * W;           // Rec<S,NL>::RECDW per step
+      const int64_t lean_dw = (int64_t)d.G * ((W * b->NL * W + 3) / 4 * 4);       // Rec<S,NL,true>::RECDW per step
+      const int64_t scratch_dw = (int64_t)(d.m + 2 * (64 / W - 1) + W) * full_rec;  // one strip: m + MAXOFF + 1 records
+      d.scratch_off = lean_dw;  // relative to layer_off until the chunk layout is fixed below
+      pair_dwords[p] = b->lean_trace ? lean_dw + scratch_dw : (b->lean ? lean_dw : (int64_t)d.G * full_rec);
+    }
+  };
+  size_pairs();
+  // A pair whose full layers exceed the budget is served from reduced storage instead of failing
+  // (memory-lean traceback, ~1.3x the time) where that mode exists: affine recurrence, LOOKUP form.
+  if (!b->lean && b->affine && !b->dense &&
+      *std::max_element(pair_dwords.begin(), pair_dwords.end()) > budget_dw) {
+    b->lean = b->lean_trace = true;
+    size_pairs();
+  }
   b->order.resize(pr->npairs);
   std::iota(b->order.begin(), b->order.end(), 0);
   b->chunk_begin.push_back(0);
@@ -363,6 +413,7 @@ int bialign_batch_create(bialign_engine* eng, const bialign_params* prm, const b
       used = 0;
     }
     b->pairs[p].layer_off = used;
+    b->pairs[p].scratch_off += used;
     used += pair_dwords[p];
     b->max_chunk_dwords = std::max(b->max_chunk_dwords, used);
   }
@@ -394,6 +445,7 @@ int bialign_batch_create(bialign_engine* eng, const bialign_params* prm, const b
   if (getenv("BIALIGN_DEBUG"))
     fprintf(stderr, "[bialign] layers %p (%.1f GiB)\n", (void*)b->d_layers.p, b->max_chunk_dwords * 4.0 / (1 << 30));
   HIP_TRY(b->d_scores.alloc(pr->npairs));
+  if (b->lean_trace) HIP_TRY(b->d_tstate.alloc(pr->npairs));
   HIP_TRY(b->d_tlen.alloc(pr->npairs));
   HIP_TRY(b->d_complete.alloc(pr->npairs));
   HIP_TRY(b->d_err.alloc(1));
@@ -434,13 +486,15 @@ int bialign_batch_get_info(const bialign_batch* b, bialign_batch_info* info) {
   info->layer_bytes = b->cells * 4 * b->NL;
   info->hbm_layer_bytes = b->max_chunk_dwords * 4;
   info->trace_bytes = b->trace_bytes;
+  info->storage = b->lean_trace ? BIALIGN_BATCH_LEAN_TRACE : (b->lean ? BIALIGN_BATCH_SCORE_ONLY : 0);
+  info->reserved = 0;
   return BIALIGN_OK;
 }
 
 int bialign_batch_run(bialign_batch* b, uint32_t flags) {
   if (!b) return fail(BIALIGN_E_INVALID, "NULL batch");
   HIP_TRY(hipSetDevice(b->eng->device));
-  const bool do_trace = !(flags & BIALIGN_RUN_FILL_ONLY) && !b->lean;
+  const bool do_trace = !(flags & BIALIGN_RUN_FILL_ONLY) && (!b->lean || b->lean_trace);
   const DeviceBatch v = b->view();
   hipStream_t st = b->eng->stream;
   hipEvent_t* ev = b->eng->ev;
@@ -452,8 +506,11 @@ int bialign_batch_run(bialign_batch* b, uint32_t flags) {
     int rc = launch_fill(b, v, first, count);
     if (rc) return rc;
     HIP_TRY(hipEventRecord(ev[1], st));
-    if (!b->lean) {  // score-only batches: the sweep itself wrote the scores
+    if (!b->lean) {  // (with LEAN records the sweep itself wrote the scores)
       rc = launch_traceback(b, v, first, count, do_trace);
+      if (rc) return rc;
+    } else if (b->lean_trace && do_trace) {
+      rc = lean_traceback_rounds(b, v, first, count);
       if (rc) return rc;
     }
     HIP_TRY(hipEventRecord(ev[2], st));
@@ -493,7 +550,8 @@ int bialign_batch_get_scores(const bialign_batch* b, int32_t* scores) {
 int bialign_batch_get_traces(const bialign_batch* b, uint8_t* trace, int64_t* trace_off, int32_t* trace_len,
                              int32_t* complete) {
   if (!b || !trace || !trace_off || !trace_len || !complete) return fail(BIALIGN_E_INVALID, "NULL argument");
-  if (b->lean) return fail(BIALIGN_E_INVALID, "batch was created with BIALIGN_BATCH_SCORE_ONLY: it holds no layers to trace back");
+  if (b->lean && !b->lean_trace)
+    return fail(BIALIGN_E_INVALID, "batch was created with BIALIGN_BATCH_SCORE_ONLY: it holds no layers to trace back");
   if (!b->ran || !b->ran_trace) return fail(BIALIGN_E_INVALID, "no traceback has been run on this batch");
   HIP_TRY(hipSetDevice(b->eng->device));
   HIP_TRY(hipMemcpy(trace, b->d_trace.p, b->trace_bytes, hipMemcpyDeviceToHost));
@@ -506,7 +564,7 @@ int bialign_batch_get_traces(const bialign_batch* b, uint8_t* trace, int64_t* tr
 int bialign_batch_dump_layers(bialign_batch* b, int32_t pair, int32_t* out) {
   if (!b || !out) return fail(BIALIGN_E_INVALID, "NULL argument");
   if (pair < 0 || pair >= b->npairs) return fail(BIALIGN_E_INVALID, "pair %d out of range", pair);
-  if (b->lean) return fail(BIALIGN_E_INVALID, "batch was created with BIALIGN_BATCH_SCORE_ONLY: it holds no layers");
+  if (b->lean) return fail(BIALIGN_E_INVALID, "batch was created with reduced layer storage (SCORE_ONLY / LEAN_TRACE): it holds no full layers");
   HIP_TRY(hipSetDevice(b->eng->device));
   hipStream_t st = b->eng->stream;
   // one-pair launch out of the regular launch order (team shape and layer offset are the pair's own)

@@ -71,6 +71,7 @@ inline int ghost_blk(int S) {
 using bialign::DevBuf;
 using bialign::DeviceBatch;
 using bialign::PairDesc;
+using bialign::TraceState;
 
 struct bialign_engine {
   int device = 0;
@@ -101,7 +102,9 @@ struct bialign_batch {
   DevBuf<uint8_t> d_seq_a, d_cls_a, d_seq_b, d_cls_b, d_trace;
   DevBuf<int32_t> d_mu2;  // dense-mu2 mode: all pairs' n x m tables
   bool dense = false;
-  bool lean = false;  // score-only batch: LEAN records (bottom rows only), no traceback possible
+  bool lean = false;        // LEAN records: the sweep keeps only the strip-bottom rows
+  bool lean_trace = false;  // ... and tracebacks re-sweep one strip at a time into a scratch area
+  DevBuf<TraceState> d_tstate;
   int k1 = 0, k2 = 0;
   bialign_timing timing{};
   bool ran = false, ran_trace = false;
@@ -121,6 +124,8 @@ struct bialign_batch {
     v.complete = d_complete.p;
     v.errflag = d_err.p;
     v.mu2_dense = dense ? d_mu2.p : nullptr;
+    v.scratch = d_layers.p;  // a pair's scratch records follow its LEAN records in the same buffer
+    v.tstate = d_tstate.p;
     return v;
   }
 };
@@ -187,6 +192,39 @@ int launch_fill_affine_l(bialign_batch* b, const DeviceBatch& v, int first, int 
 template <int S>
 int launch_fill_affine(bialign_batch* b, const DeviceBatch& v, int first, int count) {
   return b->lean ? launch_fill_affine_l<S, true>(b, v, first, count) : launch_fill_affine_l<S, false>(b, v, first, count);
+}
+
+// Lean traceback, one round: re-sweep the strip every unfinished pair's walk stands in ...
+template <int S>
+int launch_resweep_affine(bialign_batch* b, const DeviceBatch& v, int first, int count) {
+  DeviceBatch w = v;
+  w.order = v.order + first;
+  w.team = 1;
+  const size_t lds = b->lds_base + b->lds_per_wave;
+  auto go = [&](auto kern) -> int {
+    if (lds > 64 * 1024)
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3(count), dim3(64), lds, b->eng->stream, w);
+    HIP_TRY(hipGetLastError());
+    return BIALIGN_OK;
+  };
+  return b->prm.gap_opening_cost > 0 ? go(fill_affine_kernel<S, false, 1, false, false, false, true>)
+                                     : go(fill_affine_kernel<S, true, 1, false, false, false, true>);
+}
+
+// ... then walk through it.
+template <int S>
+int launch_traceback_affine_strip(const bialign_batch* b, const DeviceBatch& v, int first, int count) {
+  DeviceBatch w = v;
+  w.order = v.order + first;
+  auto kern = traceback_affine_kernel<S, true, true>;
+  if (b->lds_trace > 64 * 1024)
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_trace));
+  hipLaunchKernelGGL(kern, dim3(count), dim3(64), b->lds_trace, b->eng->stream, w, count);
+  HIP_TRY(hipGetLastError());
+  return BIALIGN_OK;
 }
 
 template <int S>
@@ -265,10 +303,13 @@ int launch_dump(const bialign_batch* b, const DeviceBatch& v, int pid, int32_t* 
 }
 
 // ---- instantiation plan: kind 0 = affine fill (the big kernels), kind 1 = everything else
-#define BIALIGN_INST_KIND0(S, X) X template int launch_fill_affine<S>(bialign_batch*, const DeviceBatch&, int, int);
+#define BIALIGN_INST_KIND0(S, X)                                                                \
+  X template int launch_fill_affine<S>(bialign_batch*, const DeviceBatch&, int, int);          \
+  X template int launch_resweep_affine<S>(bialign_batch*, const DeviceBatch&, int, int);
 #define BIALIGN_INST_KIND1(S, X)                                                                         \
   X template int launch_fill_linear<S>(bialign_batch*, const DeviceBatch&, int, int);                   \
   X template int launch_traceback_affine<S>(const bialign_batch*, const DeviceBatch&, int, int, bool);  \
+  X template int launch_traceback_affine_strip<S>(const bialign_batch*, const DeviceBatch&, int, int);  \
   X template int launch_traceback_linear<S>(const bialign_batch*, const DeviceBatch&, int, int, bool);  \
   X template int launch_dump<S, 9>(const bialign_batch*, const DeviceBatch&, int, int32_t*);            \
   X template int launch_dump<S, 1>(const bialign_batch*, const DeviceBatch&, int, int32_t*);

@@ -59,6 +59,17 @@ struct PairDesc {
   int64_t layer_off;      // dword offset of this pair's records in the chunk buffer
   int64_t trace_off;      // byte offset in the trace buffer
   int64_t mu2_off;        // dense-mu2 mode: start of this pair's n x m table
+  int64_t scratch_off;    // lean traceback: dword offset of this pair's one-strip scratch records
+};
+
+// Lean traceback: where a pair's walk stands between two strips.
+struct TraceState {
+  int32_t i, j, k, l;     // current lattice point
+  int32_t st, cur;        // its state and layer value
+  int32_t d0, d1;         // running shifts (pyx:541-545)
+  int32_t len;            // columns emitted so far (end -> start order)
+  int32_t strip;          // strip the current point lies in
+  int32_t started, done;  // 0/1
 };
 
 struct DeviceBatch {
@@ -77,6 +88,8 @@ struct DeviceBatch {
   const int32_t* mu2_dense;  // dense-mu2 mode: mu2(k,l) tables (else nullptr: LOOKUP form)
   int32_t* prog;        // cross-CU teams: [pairs in launch][64] progress words, zeroed per launch
   int32_t team;         // cross-CU teams: workgroups (= waves) per pair
+  int32_t* scratch;     // lean traceback: full records of ONE strip per pair
+  TraceState* tstate;   // lean traceback: [npairs]
 };
 
 template <int S>
@@ -315,9 +328,14 @@ __device__ __forceinline__ void store_chunk(int32_t* p, v4i v) {
     *reinterpret_cast<v4i*>(p) = v;
 }
 
-template <int S, bool BETA_NONPOS, int TW, bool XCU, bool DENSE = false, bool LEAN = false>
+//   RESW (lean traceback): re-sweep ONE strip of a pair -- the strip its walk is about to enter,
+//   TraceState::strip -- with the ghost row taken from the LEAN records of the strip above and
+//   the full records written to the pair's scratch area (record = step within the strip); only
+//   the columns up to the walk's entry column are swept.  One wave per pair.
+template <int S, bool BETA_NONPOS, int TW, bool XCU, bool DENSE = false, bool LEAN = false, bool RESW = false>
 __global__ void __launch_bounds__(64 * TW) fill_affine_kernel(const DeviceBatch A) {
   static_assert(!XCU || TW == 1, "cross-CU teams are built from one-wave workgroups");
+  static_assert(!RESW || (TW == 1 && !XCU && !LEAN && !DENSE), "strip re-sweeps: one wave, LOOKUP form, full records");
   using G_ = Geo<S>;
   using R_ = Rec<S, 9, LEAN>;
   constexpr int W = G_::W, R = G_::R, RR = G_::RR, PADB = G_::PADB;
@@ -330,6 +348,13 @@ __global__ void __launch_bounds__(64 * TW) fill_affine_kernel(const DeviceBatch 
   const int pid = A.order[slot];
   const PairDesc pd = A.pairs[pid];
   const int n = pd.n, m = pd.m, P = pd.P;
+  int Qbase = 0, jlim = m;  // RESW: the strip to sweep, the last column the walk can still reach
+  if (RESW) {
+    const TraceState ts0 = A.tstate[pid];
+    if (ts0.done) return;
+    Qbase = ts0.started ? ts0.strip : pd.NS - 1;
+    jlim = ts0.started ? ts0.j : m;
+  }
   const int L = threadIdx.x & 63;
   const int wl = TW == 1 ? 0 : __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave in workgroup
   const int w = XCU ? (int)(blockIdx.x - slot * T) : wl;                              // wave in team
@@ -342,7 +367,7 @@ __global__ void __launch_bounds__(64 * TW) fill_affine_kernel(const DeviceBatch 
 
   // ---- LDS carve-up: per wave a ghost ring and an exchange array; shared: progress
   //      words, score tables, sequence codes
-  using GF = GhostFeed<S, 9, LEAN>;
+  using GF = GhostFeed<S, 9, LEAN || RESW>;  // a re-sweep replays LEAN records
   using MF = Mu2Feed<S>;
   constexpr int PERW = GF::RING_DW + NV * NCOL + (DENSE ? MF::RING_DW : 0);  // dwords per wave
   v4i* ring = reinterpret_cast<v4i*>(smem + wl * GF::RING_DW);   // ghost-row ring, two halves
@@ -378,12 +403,13 @@ __global__ void __launch_bounds__(64 * TW) fill_affine_kernel(const DeviceBatch 
   const int colLW1 = (live && il >= 1 && aa < W - 1) ? L - W + 1 : 64; // (i-1, a+1)
   const bool a_first = (aa == 0);  // no (i, a-1) inside the band: lane L-1 is another row
   const int GOFF = P - 2 * (R - 1);  // steps between a bottom row and its ghost copy
-  int32_t* const lay = A.layers + pd.layer_off;
+  int32_t* const lay = A.layers + pd.layer_off;                       // records the ghost feed replays
+  int32_t* const sto = RESW ? A.scratch + pd.scratch_off : lay;       // records this sweep writes
 
   const int rec_last = pd.G - 1;     // last record of this pair
   // local steps of this wave: its strips are w, w+T, ... (NSw of them)
-  const int NSw = (pd.NS - w + T - 1) / T;
-  const int H = NSw > 0 ? (NSw - 1) * P + m + G_::MAXOFF + 1 : 0;
+  const int NSw = RESW ? 1 : (pd.NS - w + T - 1) / T;
+  const int H = NSw > 0 ? (NSw - 1) * P + (RESW ? jlim : m) + G_::MAXOFF + 1 : 0;
 
   // ---- per-lane sweep state
   int jj = -(2 * il + aa);  // column of this step (< 0: not started)
@@ -392,7 +418,7 @@ __global__ void __launch_bounds__(64 * TW) fill_affine_kernel(const DeviceBatch 
   int i = 0, s1row = 0, s2row = 0;
   bool act_row = false;
   auto set_row = [&](int q) {
-    i = (q * T + w) * RR + il - 1;
+    i = (Qbase + q * T + w) * RR + il - 1;
     const int k = i + aa - S;
     act_row = live && i >= 0 && i <= n && k >= 0 && k <= n;
     s1row = (i >= 1 && i <= n) ? sa[i - 1] * k1 : 0;
@@ -462,7 +488,7 @@ __global__ void __launch_bounds__(64 * TW) fill_affine_kernel(const DeviceBatch 
     // h0 = first local step of the block (this lane is then at column jj0, before wrapping);
     // blk_q/blk_rem describe h0
     wait_partner(h0 + GF::BLK - 1);
-    GF::issue(lay, h0, blk_q, blk_rem, P, T, w, GOFF, rec_last, L, ring_lds + half * GF::SLOTS * 16);
+    GF::issue(lay, h0 + Qbase * P, blk_q, blk_rem, P, T, w, GOFF, rec_last, L, ring_lds + half * GF::SLOTS * 16);
     if (DENSE) MF::issue(mu2tab, n, m, P, jj0, strip, T, w, il, aa, mu2_lds + half * MF::BLK * 256);
     blk_rem += GF::BLK;
     if (blk_rem >= P) { blk_rem -= P; ++blk_q; }
@@ -546,7 +572,7 @@ __global__ void __launch_bounds__(64 * TW) fill_affine_kernel(const DeviceBatch 
     if (__builtin_amdgcn_ballot_w64(do_store) != 0) vm_younger += GF::STORES_PER_STEP;
     int32_t* const dst = BIALIGN_EXP == 2
                              ? A.layers + ((int64_t)(blockIdx.x & 255) << 18) + (int64_t)(g & 31) * RECDW
-                             : lay + (int64_t)rec * RECDW;
+                             : sto + (int64_t)rec * RECDW;
 
     // ---- 3. the W lattice points of this (i, j, a)
     int outv[ND];
@@ -733,7 +759,7 @@ __global__ void __launch_bounds__(64 * TW) fill_affine_kernel(const DeviceBatch 
 
     // ---- 6. advance
     ++jj;
-    if (jj == P) {
+    if (!RESW && jj == P) {  // a re-sweep ends inside its one strip
       jj = 0;
       ++strip;
       rec_base += (T - 1) * P;
@@ -813,7 +839,11 @@ __device__ __forceinline__ int wave_min16(int v) {  // min over lanes 0..15, val
   return v;
 }
 
-template <int S, bool DO_TRACE>
+//   STRIP (lean traceback): the walk continues from the pair's
+//   TraceState through ONE strip -- the one fill_affine_kernel<.., RESW> has just re-swept into
+//   the scratch records -- and stops when it steps into the strip above (whose bottom row, the
+//   only row of it a candidate can touch from here, is in the LEAN records) or ends.
+template <int S, bool DO_TRACE, bool STRIP = false>
 __global__ void __launch_bounds__(64) traceback_affine_kernel(const DeviceBatch A, int npairs) {
   const int pid = A.order[blockIdx.x];
   const PairDesc pd = A.pairs[pid];
@@ -822,26 +852,50 @@ __global__ void __launch_bounds__(64) traceback_affine_kernel(const DeviceBatch 
   const int32_t* lay = A.layers;
   const int c = threadIdx.x;  // candidate lane
   constexpr int BIG = 0x7fffffff;
+  constexpr int W = 2 * S + 1, RR = Geo<S>::RR;
   extern __shared__ __align__(16) int32_t smem[];
 
-  // pyx:573-582: best end layer, first one with the least shift
-  const int endv = c < 9 ? lay[cell_dword<S, 9>(pd, n, m, S, S, c)] : -BIG;
-  const int best = __builtin_amdgcn_readfirstlane(-wave_min16(-endv));
-  if (c == 0) A.scores[pid] = best;
-  if (!DO_TRACE) return;
-  const int skey = (c < 9 && endv == best) ? (shift_of(c / 3, c % 3) << 4 | c) : BIG;
-  int st = __builtin_amdgcn_readfirstlane(wave_min16(skey)) & 15;
+  TraceState ts{};
+  if (STRIP) {
+    ts = A.tstate[pid];
+    if (ts.done) return;
+  }
+  const int Q = STRIP ? (ts.started ? ts.strip : pd.NS - 1) : 0;
+  // layer value (state ss) of lattice point (pi, pj, a, b)
+  auto cell = [&](int pi, int pj, int a, int b, int ss) -> int {
+    if (!STRIP) return lay[cell_dword<S, 9>(pd, pi, pj, a, b, ss)];
+    const int sp = pi / RR, ilp = pi - sp * RR + 1;
+    if (sp == Q)  // inside the re-swept strip: record = step within the strip
+      return A.scratch[pd.scratch_off + Rec<S, 9>::dword(pj + 2 * ilp + a, (ilp - 1) * W + a, b * 9 + ss)];
+    // bottom row of the strip above (ilp == RR): LEAN record of its global step
+    return lay[pd.layer_off + Rec<S, 9, true>::dword((int64_t)sp * pd.P + pj + 2 * ilp + a, a, b * 9 + ss)];
+  };
+
+  int i = n, j = m, k = n, l = m, d0 = 0, d1 = 0, len = 0, complete = 0;
+  int st = 0, cur = 0;
+  if (!STRIP || !ts.started) {
+    // pyx:573-582: best end layer, first one with the least shift
+    const int endv = c < 9 ? cell(n, m, S, S, c) : -BIG;
+    const int best = __builtin_amdgcn_readfirstlane(-wave_min16(-endv));
+    if (c == 0) A.scores[pid] = best;
+    if (!DO_TRACE) return;
+    const int skey = (c < 9 && endv == best) ? (shift_of(c / 3, c % 3) << 4 | c) : BIG;
+    st = __builtin_amdgcn_readfirstlane(wave_min16(skey)) & 15;
+    cur = best;
+  } else {
+    i = ts.i; j = ts.j; k = ts.k; l = ts.l; st = ts.st; cur = ts.cur; d0 = ts.d0; d1 = ts.d1; len = ts.len;
+  }
   const TraceInputs in = stage_trace_inputs(A, pd, smem);
   const uint8_t *sa = in.sa, *ca = in.ca, *sb = in.sb, *cb = in.cb;
 
   uint8_t* out = A.trace + pd.trace_off;
-  int i = n, j = m, k = n, l = m, d0 = 0, d1 = 0, len = 0, complete = 0;
-  int cur = best;
+  bool finished = true;  // STRIP: false when the walk merely left this strip
   // lane-constant part of the candidate: its group and, for groups 2/3, the free half h
   const int grp = c < 9 ? 1 : (c < 12 ? 2 : 3);
   const int hfree = grp == 2 ? 2 - (c - 9) : 2 - (c - 12);  // h = M, X, Y in the generator's order
   while (true) {
     if (i == 0 && j == 0 && k == 0 && l == 0 && st == 8) { complete = 1; break; }
+    if (STRIP && i < Q * RR) { finished = false; break; }  // now in the strip above: re-sweep it first
     const int hU = st / 3, hV = st - 3 * hU;
     const int u0 = hU >= 1, u1 = hU != 1, v0 = hV >= 1, v1 = hV != 1;
     const int mu1 = (i >= 1 && j >= 1) ? in.s1[sa[i - 1] * A.k1 + sb[j - 1]] : 0;
@@ -863,7 +917,7 @@ __global__ void __launch_bounds__(64) traceback_affine_kernel(const DeviceBatch 
     const int pi = i - o0, pj = j - o1, pk = k - o2, pl = l - o3;
     const bool ok = c < 15 && pi >= 0 && pj >= 0 && pk >= 0 && pl >= 0 && abs(pk - pi) <= S &&
                     abs(pl - pj) <= S;  // pyx:133-141
-    const int ld = ok ? lay[cell_dword<S, 9>(pd, pi, pj, pk - pi + S, pl - pj + S, ss)] : 0;
+    const int ld = ok ? cell(pi, pj, pk - pi + S, pl - pj + S, ss) : 0;
     // pyx:554-565: cases reproducing the cell; look-ahead adds the offset AND the source state
     const int r0 = ra >= 1, r1 = ra != 1, r2 = rb >= 1, r3 = rb != 1;
     const int t0 = d0 + (o0 - o2) + (r0 - r2), t1 = d1 + (o1 - o3) + (r1 - r3);
@@ -881,6 +935,15 @@ __global__ void __launch_bounds__(64) traceback_affine_kernel(const DeviceBatch 
     ++len;
     i -= q0; j -= q1; k -= q2; l -= q3;
   }
+  if (STRIP && !finished) {  // hand over to the next round
+    if (c == 0) {
+      TraceState nx;
+      nx.i = i; nx.j = j; nx.k = k; nx.l = l; nx.st = st; nx.cur = cur; nx.d0 = d0; nx.d1 = d1;
+      nx.len = len; nx.strip = Q - 1; nx.started = 1; nx.done = 0;
+      A.tstate[pid] = nx;
+    }
+    return;
+  }
   if (len > pd.trace_cap) len = pd.trace_cap;
   __builtin_amdgcn_s_waitcnt(0);  // lane 0's byte stores before the wave-wide reversal
   __syncthreads();
@@ -892,6 +955,11 @@ __global__ void __launch_bounds__(64) traceback_affine_kernel(const DeviceBatch 
   if (c == 0) {
     A.trace_len[pid] = len;
     A.complete[pid] = complete;
+    if (STRIP) {
+      ts.done = 1;
+      ts.started = 1;
+      A.tstate[pid] = ts;
+    }
   }
 }
 

@@ -68,10 +68,13 @@ class Batch:
     [k-1, l-1] = mu2(k, l); replaces the class codes / ``s2`` (DENSE form of include/bialign.h).
     ``score_only``: the batch will never be traced back (BIALIGN_BATCH_SCORE_ONLY): the sweep keeps
     only the rows the next strip needs; ``traces()`` / ``dump_layers()`` raise.
+    ``lean_trace``: scores AND traces from that reduced storage (BIALIGN_BATCH_LEAN_TRACE): the
+    traceback re-sweeps one strip at a time; for pairs whose full layers would not fit in HBM.
     """
 
     def __init__(self, engine, mols_a, mols_b, s1, s2, gap_opening_cost, gap_cost, shift_cost,
-                 max_shift, hbm_budget_bytes=0, recurrence=0, mu2_dense=None, score_only=False):
+                 max_shift, hbm_budget_bytes=0, recurrence=0, mu2_dense=None, score_only=False,
+                 lean_trace=False):
         if len(mols_a) != len(mols_b) or not mols_a:
             raise ValueError("need the same, non-zero number of A and B molecules")
         self.engine = engine
@@ -110,7 +113,8 @@ class Batch:
             mu2_flat = np.ascontiguousarray(np.concatenate(flat))
             mu2_ptr, mu2_off_ptr = _ptr(mu2_flat, ctypes.c_int32), _ptr(mu2_off, ctypes.c_int64)
         prm = _lib.Params(int(gap_opening_cost), int(gap_cost), int(shift_cost), int(max_shift),
-                          int(recurrence), _lib.BATCH_SCORE_ONLY if score_only else 0)
+                          int(recurrence), (_lib.BATCH_SCORE_ONLY if score_only else 0) |
+                          (_lib.BATCH_LEAN_TRACE if lean_trace else 0))
         sc = _lib.Scoring(s1.shape[0], _ptr(s1, ctypes.c_int32), s2.shape[0], _ptr(s2, ctypes.c_int32))
         pr = _lib.Pairs(self.npairs, _ptr(self.len_a, ctypes.c_int32), _ptr(self.len_b, ctypes.c_int32),
                         _ptr(off_a, ctypes.c_int64), _ptr(off_b, ctypes.c_int64),

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define BIALIGN_ABI_VERSION 6
+#define BIALIGN_ABI_VERSION 7
 
 #define BIALIGN_OK 0
 #define BIALIGN_E_INVALID (-1)     /* bad argument (message says which) */
@@ -56,6 +56,11 @@ extern "C" {
  * next strip needs instead of all layers -- 1/20 of the HBM footprint and traffic at max_shift 1 --
  * and bialign_batch_get_traces / bialign_batch_dump_layers fail with BIALIGN_E_INVALID. */
 #define BIALIGN_BATCH_SCORE_ONLY 1u
+/* LEAN_TRACE: full results (scores and traces) from the same reduced storage: after the lean sweep
+ * the traceback re-sweeps one strip of lattice rows at a time into a small per-pair scratch area
+ * and walks through it.  About a tenth of the HBM footprint of the default mode for ~1.3x the time:
+ * for pairs whose layers would not fit otherwise.  Affine recurrence, LOOKUP form. */
+#define BIALIGN_BATCH_LEAN_TRACE 2u
 
 typedef struct bialign_engine bialign_engine; /* one per (process, device) */
 typedef struct bialign_batch bialign_batch;   /* inputs resident in HBM */
@@ -109,6 +114,9 @@ typedef struct bialign_batch_info {
   int64_t layer_bytes;    /* algorithmic bytes: 36 B (affine) or 4 B per cell */
   int64_t hbm_layer_bytes;/* allocated size of the largest chunk's layer buffer */
   int64_t trace_bytes;    /* capacity of the trace buffer, sum of 2(n+m)+2 */
+  int32_t storage;        /* 0 = all layers, BIALIGN_BATCH_SCORE_ONLY, or BIALIGN_BATCH_LEAN_TRACE (asked for, or
+                             chosen by the engine because a pair's full layers exceed the HBM budget) */
+  int32_t reserved;
 } bialign_batch_info;
 
 typedef struct bialign_timing {

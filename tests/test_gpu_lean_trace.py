@@ -1,0 +1,108 @@
+"""Memory-lean traceback (BIALIGN_BATCH_LEAN_TRACE): lean sweep, then per strip a re-sweep into a
+scratch area and a walk through it.  Scores, traces and completeness flags must equal the default
+path's (which the other GPU tests pin to the oracle and the golden vectors)."""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from bialign_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def run(pairs, params, **kw):
+    from bialign_amd.batch import make_batch
+    b = make_batch(pairs, params, **kw)
+    b.run()
+    traces, ok = b.traces()
+    out = (b.scores().copy(), [t.tolist() for t in traces], [bool(v) for v in ok], dict(b.info), b.timing())
+    b.close()
+    return out
+
+
+def same(pairs, params, **kw):
+    full = run(pairs, params, **kw)
+    lean = run(pairs, params, lean_trace=True, **kw)
+    np.testing.assert_array_equal(lean[0], full[0])
+    for t, (a, b) in enumerate(zip(lean[1], full[1])):
+        assert a == b, f"pair {t}: traces differ"
+    assert lean[2] == full[2]
+    return full, lean
+
+
+@pytest.mark.parametrize("s", [0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize("beta", [-150, 100], ids=["beta<0", "beta>0"])
+def test_random_shapes_equal_default_path(s, beta):
+    rng = np.random.default_rng(40 + s)
+    shapes = [(int(rng.integers(1, 140)), int(rng.integers(1, 140))) for _ in range(20)] + \
+             [(1, 1), (64, 64), (63, 1), (1, 90), (200, 7), (7, 200)]
+    pairs = [synth.protein_pair(1200 + t, n, m) for t, (n, m) in enumerate(shapes)]
+    same(pairs, dict(synth.PROTEIN_PARAMS, max_shift=s, gap_opening_cost=beta))
+
+
+@pytest.mark.parametrize("n,m,s", [(500, 480, 1), (300, 650, 1), (650, 300, 1), (420, 400, 0), (257, 300, 2),
+                                    (200, 210, 3), (1500, 40, 1), (40, 1500, 1)])
+def test_many_strips(n, m, s):
+    pairs = [synth.protein_pair(1300 + t, n - 3 * t, m + 2 * t) for t in range(3)]
+    full, lean = same(pairs, dict(synth.PROTEIN_PARAMS, max_shift=s))
+    if n >= 250:  # many strips: one strip of scratch plus the bottom rows is a fraction of all layers
+        assert lean[3]["hbm_layer_bytes"] * 3 < full[3]["hbm_layer_bytes"]
+
+
+def test_golden_rna_and_protein_cases():
+    for rec in load_golden("medium_traces.json") + load_golden("known_answers.json"):
+        p = rec["params"]
+        if p["gap_opening_cost"] == 0 or p["max_shift"] > 5:
+            continue
+        from bialign_amd.engine import trace_codes_to_columns
+        got = run([(rec["seqA"], rec["seqB"], rec["strA"], rec["strB"])], p, lean_trace=True)
+        assert int(got[0][0]) == rec["score"]
+        assert trace_codes_to_columns(np.array(got[1][0], dtype=np.uint8)) == rec["trace"]
+        assert got[2][0] == rec["complete"]
+
+
+def test_chunked_and_ragged():
+    shapes = [(300, 280), (5, 90), (90, 5), (64, 64), (1, 1), (170, 180), (100, 100), (2, 50), (260, 30)]
+    pairs = [synth.protein_pair(1400 + t, n, m) for t, (n, m) in enumerate(shapes)]
+    params = dict(synth.PROTEIN_PARAMS)
+    full = run(pairs, params)
+    lean = run(pairs, params, lean_trace=True, hbm_budget_bytes=6 << 20)
+    assert lean[3]["nchunks"] > 1
+    np.testing.assert_array_equal(lean[0], full[0])
+    assert lean[1] == full[1] and lean[2] == full[2]
+
+
+def test_refusals():
+    from bialign_amd.batch import make_batch
+    from bialign_amd._lib import BialignError
+    pair = synth.protein_pair(1, 30, 30)
+    with pytest.raises(BialignError):  # non-affine recurrence
+        make_batch([pair], dict(synth.PROTEIN_PARAMS, gap_opening_cost=0), lean_trace=True)
+    b = make_batch([pair], dict(synth.PROTEIN_PARAMS), lean_trace=True)
+    b.run()
+    with pytest.raises(BialignError):
+        b.dump_layers(0)
+    b.close()
+
+
+def test_config2_shape_sample_and_timing():
+    pairs = synth.protein_batch(256, 512)
+    full, lean = same(pairs, dict(synth.PROTEIN_PARAMS))
+    print(f"full: fill {full[4]['fill_ms']:.2f} tb {full[4]['traceback_ms']:.2f} ms, {full[3]['hbm_layer_bytes'] / 2**30:.1f} GiB | "
+          f"lean: fill {lean[4]['fill_ms']:.2f} tb {lean[4]['traceback_ms']:.2f} ms, {lean[3]['hbm_layer_bytes'] / 2**30:.1f} GiB")
+
+
+def test_engine_falls_back_to_lean_traceback_when_a_pair_exceeds_the_budget():
+    """Instead of BIALIGN_E_NOMEM: same results from reduced storage (affine, LOOKUP form)."""
+    from bialign_amd._lib import BATCH_LEAN_TRACE, BialignError
+    from bialign_amd.batch import make_batch
+    pairs = [synth.protein_pair(1500 + t, 400, 380) for t in range(2)]
+    params = dict(synth.PROTEIN_PARAMS)
+    full = run(pairs, params)
+    assert full[3]["storage"] == 0
+    lean = run(pairs, params, hbm_budget_bytes=12 << 20)   # full layers of one pair: ~50 MB
+    assert lean[3]["storage"] == BATCH_LEAN_TRACE
+    np.testing.assert_array_equal(lean[0], full[0])
+    assert lean[1] == full[1] and lean[2] == full[2]
+    with pytest.raises(BialignError):   # the one-layer recurrence has no such mode: still an error
+        make_batch(pairs, dict(params, gap_opening_cost=0), hbm_budget_bytes=1 << 20)
