@@ -156,6 +156,7 @@ int lean_traceback_rounds(bialign_batch* b, const DeviceBatch& v, int first, int
   HIP_TRY(hipMemsetAsync(b->d_tstate.p, 0, sizeof(TraceState) * b->npairs, st));
   int rounds = 0;
   for (int t = first; t < first + count; ++t) rounds = std::max(rounds, b->pairs[b->order[t]].NS);
+  rounds = (rounds + b->resw_k - 1) / b->resw_k;
   for (int r = 0; r < rounds; ++r) {
     int rc = BIALIGN_E_UNSUPPORTED;
     switch (b->S) {
@@ -381,16 +382,24 @@ int bialign_batch_create(bialign_engine* eng, const bialign_params* prm, const b
       const int64_t lean_dw = (int64_t)d.G * ((W * b->NL * W + 3) / 4 * 4);       // Rec<S,NL,true>::RECDW per step
       const int64_t scratch_dw = (int64_t)(d.m + 2 * (64 / W - 1) + W) * full_rec;  // one strip: m + MAXOFF + 1 records
       d.scratch_off = lean_dw;  // relative to layer_off until the chunk layout is fixed below
-      pair_dwords[p] = b->lean_trace ? lean_dw + scratch_dw : (b->lean ? lean_dw : (int64_t)d.G * full_rec);
+      pair_dwords[p] = b->lean_trace ? lean_dw + b->resw_k * scratch_dw : (b->lean ? lean_dw : (int64_t)d.G * full_rec);
     }
   };
+  // lean traceback: few pairs -> several strips per round (they re-sweep in parallel), as memory allows
+  auto pick_resw_k = [&]() {
+    b->resw_k = (int)std::min<int64_t>(32, std::max<int64_t>(1, 2048 / pr->npairs));
+    if (const char* e = getenv("BIALIGN_RESW_K")) b->resw_k = std::min(32, std::max(1, atoi(e)));  // tests
+    for (size_pairs(); b->resw_k > 1 && *std::max_element(pair_dwords.begin(), pair_dwords.end()) > budget_dw; size_pairs())
+      b->resw_k /= 2;
+  };
+  if (b->lean_trace) pick_resw_k();
   size_pairs();
   // A pair whose full layers exceed the budget is served from reduced storage instead of failing
   // (memory-lean traceback, ~1.3x the time) where that mode exists: affine recurrence, LOOKUP form.
   if (!b->lean && b->affine && !b->dense &&
       *std::max_element(pair_dwords.begin(), pair_dwords.end()) > budget_dw) {
     b->lean = b->lean_trace = true;
-    size_pairs();
+    pick_resw_k();
   }
   b->order.resize(pr->npairs);
   std::iota(b->order.begin(), b->order.end(), 0);

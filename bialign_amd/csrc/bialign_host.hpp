@@ -105,6 +105,7 @@ struct bialign_batch {
   bool lean = false;        // LEAN records: the sweep keeps only the strip-bottom rows
   bool lean_trace = false;  // ... and tracebacks re-sweep one strip at a time into a scratch area
   DevBuf<TraceState> d_tstate;
+  int resw_k = 1;           // strips re-swept and walked per round (more when the batch has few pairs)
   int k1 = 0, k2 = 0;
   bialign_timing timing{};
   bool ran = false, ran_trace = false;
@@ -126,6 +127,7 @@ struct bialign_batch {
     v.mu2_dense = dense ? d_mu2.p : nullptr;
     v.scratch = d_layers.p;  // a pair's scratch records follow its LEAN records in the same buffer
     v.tstate = d_tstate.p;
+    v.resw_k = resw_k;
     return v;
   }
 };
@@ -205,7 +207,7 @@ int launch_resweep_affine(bialign_batch* b, const DeviceBatch& v, int first, int
     if (lds > 64 * 1024)
       HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, dim3(count), dim3(64), lds, b->eng->stream, w);
+    hipLaunchKernelGGL(kern, dim3(count * b->resw_k), dim3(64), lds, b->eng->stream, w);
     HIP_TRY(hipGetLastError());
     return BIALIGN_OK;
   };

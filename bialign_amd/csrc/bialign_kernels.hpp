@@ -88,8 +88,9 @@ struct DeviceBatch {
   const int32_t* mu2_dense;  // dense-mu2 mode: mu2(k,l) tables (else nullptr: LOOKUP form)
   int32_t* prog;        // cross-CU teams: [pairs in launch][64] progress words, zeroed per launch
   int32_t team;         // cross-CU teams: workgroups (= waves) per pair
-  int32_t* scratch;     // lean traceback: full records of ONE strip per pair
+  int32_t* scratch;     // lean traceback: full records of resw_k strips per pair
   TraceState* tstate;   // lean traceback: [npairs]
+  int32_t resw_k;       // lean traceback: strips re-swept (in parallel) and walked per round
 };
 
 template <int S>
@@ -328,10 +329,11 @@ __device__ __forceinline__ void store_chunk(int32_t* p, v4i v) {
     *reinterpret_cast<v4i*>(p) = v;
 }
 
-//   RESW (lean traceback): re-sweep ONE strip of a pair -- the strip its walk is about to enter,
-//   TraceState::strip -- with the ghost row taken from the LEAN records of the strip above and
-//   the full records written to the pair's scratch area (record = step within the strip); only
-//   the columns up to the walk's entry column are swept.  One wave per pair.
+//   RESW (lean traceback): re-sweep ONE strip of a pair with the ghost row taken from the LEAN
+//   records of the strip above and the full records written to a scratch area (record = step
+//   within the strip).  Workgroup b handles pair b / K, strip TraceState::strip - b % K (K =
+//   A.resw_k strips per round, independent of each other, each into its own scratch slot); the
+//   strip the walk stands in is swept only up to the walk's column.  One wave per strip.
 template <int S, bool BETA_NONPOS, int TW, bool XCU, bool DENSE = false, bool LEAN = false, bool RESW = false>
 __global__ void __launch_bounds__(64 * TW) fill_affine_kernel(const DeviceBatch A) {
   static_assert(!XCU || TW == 1, "cross-CU teams are built from one-wave workgroups");
@@ -344,16 +346,18 @@ __global__ void __launch_bounds__(64 * TW) fill_affine_kernel(const DeviceBatch 
   extern __shared__ __align__(16) int32_t smem[];
 
   const int T = XCU ? A.team : TW;                       // team size
-  const int slot = XCU ? blockIdx.x / T : blockIdx.x;     // pair of this launch
+  const int slot = XCU ? blockIdx.x / T : (RESW ? blockIdx.x / A.resw_k : blockIdx.x);  // pair of this launch
   const int pid = A.order[slot];
   const PairDesc pd = A.pairs[pid];
   const int n = pd.n, m = pd.m, P = pd.P;
-  int Qbase = 0, jlim = m;  // RESW: the strip to sweep, the last column the walk can still reach
+  int Qbase = 0, jlim = m, kk = 0;  // RESW: the strip to sweep, the last column the walk can still reach
   if (RESW) {
     const TraceState ts0 = A.tstate[pid];
     if (ts0.done) return;
-    Qbase = ts0.started ? ts0.strip : pd.NS - 1;
-    jlim = ts0.started ? ts0.j : m;
+    kk = blockIdx.x - slot * A.resw_k;
+    Qbase = (ts0.started ? ts0.strip : pd.NS - 1) - kk;
+    if (Qbase < 0) return;
+    jlim = (ts0.started && kk == 0) ? ts0.j : m;
   }
   const int L = threadIdx.x & 63;
   const int wl = TW == 1 ? 0 : __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave in workgroup
@@ -404,7 +408,7 @@ __global__ void __launch_bounds__(64 * TW) fill_affine_kernel(const DeviceBatch 
   const bool a_first = (aa == 0);  // no (i, a-1) inside the band: lane L-1 is another row
   const int GOFF = P - 2 * (R - 1);  // steps between a bottom row and its ghost copy
   int32_t* const lay = A.layers + pd.layer_off;                       // records the ghost feed replays
-  int32_t* const sto = RESW ? A.scratch + pd.scratch_off : lay;       // records this sweep writes
+  int32_t* const sto = RESW ? A.scratch + pd.scratch_off + (int64_t)kk * (m + G_::MAXOFF + 1) * RECDW : lay;  // records this sweep writes
 
   const int rec_last = pd.G - 1;     // last record of this pair
   // local steps of this wave: its strips are w, w+T, ... (NSw of them)
@@ -861,12 +865,15 @@ __global__ void __launch_bounds__(64) traceback_affine_kernel(const DeviceBatch 
     if (ts.done) return;
   }
   const int Q = STRIP ? (ts.started ? ts.strip : pd.NS - 1) : 0;
+  const int Qlo = STRIP ? max(Q - A.resw_k + 1, 0) : 0;  // strips Qlo..Q sit in the scratch slots Q-sp
+  const int64_t sstride = (int64_t)(m + Geo<S>::MAXOFF + 1) * Rec<S, 9>::RECDW;
   // layer value (state ss) of lattice point (pi, pj, a, b)
   auto cell = [&](int pi, int pj, int a, int b, int ss) -> int {
     if (!STRIP) return lay[cell_dword<S, 9>(pd, pi, pj, a, b, ss)];
     const int sp = pi / RR, ilp = pi - sp * RR + 1;
-    if (sp == Q)  // inside the re-swept strip: record = step within the strip
-      return A.scratch[pd.scratch_off + Rec<S, 9>::dword(pj + 2 * ilp + a, (ilp - 1) * W + a, b * 9 + ss)];
+    if (sp >= Qlo)  // inside a re-swept strip: record = step within the strip
+      return A.scratch[pd.scratch_off + (Q - sp) * sstride +
+                       Rec<S, 9>::dword(pj + 2 * ilp + a, (ilp - 1) * W + a, b * 9 + ss)];
     // bottom row of the strip above (ilp == RR): LEAN record of its global step
     return lay[pd.layer_off + Rec<S, 9, true>::dword((int64_t)sp * pd.P + pj + 2 * ilp + a, a, b * 9 + ss)];
   };
@@ -895,7 +902,7 @@ __global__ void __launch_bounds__(64) traceback_affine_kernel(const DeviceBatch 
   const int hfree = grp == 2 ? 2 - (c - 9) : 2 - (c - 12);  // h = M, X, Y in the generator's order
   while (true) {
     if (i == 0 && j == 0 && k == 0 && l == 0 && st == 8) { complete = 1; break; }
-    if (STRIP && i < Q * RR) { finished = false; break; }  // now in the strip above: re-sweep it first
+    if (STRIP && i < Qlo * RR) { finished = false; break; }  // above the re-swept strips: next round
     const int hU = st / 3, hV = st - 3 * hU;
     const int u0 = hU >= 1, u1 = hU != 1, v0 = hV >= 1, v1 = hV != 1;
     const int mu1 = (i >= 1 && j >= 1) ? in.s1[sa[i - 1] * A.k1 + sb[j - 1]] : 0;
@@ -939,7 +946,7 @@ __global__ void __launch_bounds__(64) traceback_affine_kernel(const DeviceBatch 
     if (c == 0) {
       TraceState nx;
       nx.i = i; nx.j = j; nx.k = k; nx.l = l; nx.st = st; nx.cur = cur; nx.d0 = d0; nx.d1 = d1;
-      nx.len = len; nx.strip = Q - 1; nx.started = 1; nx.done = 0;
+      nx.len = len; nx.strip = Qlo - 1; nx.started = 1; nx.done = 0;
       A.tstate[pid] = nx;
     }
     return;

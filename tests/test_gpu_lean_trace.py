@@ -40,12 +40,14 @@ def test_random_shapes_equal_default_path(s, beta):
     same(pairs, dict(synth.PROTEIN_PARAMS, max_shift=s, gap_opening_cost=beta))
 
 
+@pytest.mark.parametrize("k", ["1", "2", "5", "32"])
 @pytest.mark.parametrize("n,m,s", [(500, 480, 1), (300, 650, 1), (650, 300, 1), (420, 400, 0), (257, 300, 2),
                                     (200, 210, 3), (1500, 40, 1), (40, 1500, 1)])
-def test_many_strips(n, m, s):
+def test_many_strips(n, m, s, k, monkeypatch):
+    monkeypatch.setenv("BIALIGN_RESW_K", k)   # strips re-swept and walked per round
     pairs = [synth.protein_pair(1300 + t, n - 3 * t, m + 2 * t) for t in range(3)]
     full, lean = same(pairs, dict(synth.PROTEIN_PARAMS, max_shift=s))
-    if n >= 250:  # many strips: one strip of scratch plus the bottom rows is a fraction of all layers
+    if n >= 250 and k == "1":  # many strips: one strip of scratch plus the bottom rows is a fraction of all layers
         assert lean[3]["hbm_layer_bytes"] * 3 < full[3]["hbm_layer_bytes"]
 
 
@@ -106,3 +108,20 @@ def test_engine_falls_back_to_lean_traceback_when_a_pair_exceeds_the_budget():
     assert lean[1] == full[1] and lean[2] == full[2]
     with pytest.raises(BialignError):   # the one-layer recurrence has no such mode: still an error
         make_batch(pairs, dict(params, gap_opening_cost=0), hbm_budget_bytes=1 << 20)
+
+
+def test_single_long_pair_many_strips_per_round():
+    """One 3000 x 2800 pair: 32 strips per round re-swept by 32 waves in parallel."""
+    pairs = [synth.protein_pair(1600, 3000, 2800)]
+    full, lean = same(pairs, dict(synth.PROTEIN_PARAMS))
+    print(f"full: fill {full[4]['fill_ms']:.1f} tb {full[4]['traceback_ms']:.1f} ms | lean: fill {lean[4]['fill_ms']:.1f} "
+          f"tb {lean[4]['traceback_ms']:.1f} ms; layers {full[3]['hbm_layer_bytes'] >> 20} -> {lean[3]['hbm_layer_bytes'] >> 20} MiB")
+
+
+def test_one_pair_of_length_twenty_thousand():
+    """130 GB of layers in the default mode, 7 GB here: same score, same 40 000-column trace."""
+    pairs = [synth.protein_pair(1700, 20000, 19000)]
+    full, lean = same(pairs, dict(synth.PROTEIN_PARAMS))
+    assert lean[3]["hbm_layer_bytes"] * 8 < full[3]["hbm_layer_bytes"]
+    print(f"full: fill {full[4]['fill_ms']:.0f} tb {full[4]['traceback_ms']:.0f} ms, {full[3]['hbm_layer_bytes'] / 2**30:.1f} GiB | "
+          f"lean: fill {lean[4]['fill_ms']:.0f} tb {lean[4]['traceback_ms']:.0f} ms, {lean[3]['hbm_layer_bytes'] / 2**30:.1f} GiB")
