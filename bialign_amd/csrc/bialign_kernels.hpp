@@ -42,6 +42,9 @@
 // interior step variant, 4 = always take it
 #define BIALIGN_EXP 0
 #endif
+#ifndef BIALIGN_OPT  // A/B switches of equivalent step code: 1 = fused DPP-min exchange, 2 = ghost rows by branch
+#define BIALIGN_OPT 3
+#endif
 
 namespace bialign {
 
@@ -270,6 +273,7 @@ struct Mu2Feed {
 };
 
 __device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
+__device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
 // f_T for the three target halves; arguments are the values for source half Y, X, M.
 __device__ __forceinline__ int fM(int y, int x, int m) { return imax(imax(y, x), m); }
 __device__ __forceinline__ int fX(int y, int x, int m, int beta) { return imax(x, beta + imax(y, m)); }
@@ -406,6 +410,7 @@ __global__ void __launch_bounds__(64 * TW) fill_affine_kernel(const DeviceBatch 
   const int colLW = (live && il >= 1) ? L - W : 64;                    // (i-1, a)
   const int colLW1 = (live && il >= 1 && aa < W - 1) ? L - W + 1 : 64; // (i-1, a+1)
   const bool a_first = (aa == 0);  // no (i, a-1) inside the band: lane L-1 is another row
+  const int lane_cap = a_first ? SENT : 0x7fffffff;  // min() with it = "sentinel where a-1 leaves the band"
   const int GOFF = P - 2 * (R - 1);  // steps between a bottom row and its ghost copy
   int32_t* const lay = A.layers + pd.layer_off;                       // records the ghost feed replays
   int32_t* const sto = RESW ? A.scratch + pd.scratch_off + (int64_t)kk * (m + G_::MAXOFF + 1) * RECDW : lay;  // records this sweep writes
@@ -531,13 +536,45 @@ __global__ void __launch_bounds__(64 * TW) fill_affine_kernel(const DeviceBatch 
       for (int x = 0; x < 4; ++x) inA[r][x] = xch[(r * XR + x) * NCOL + colLW];
 #pragma unroll
       for (int x = 0; x < 8; ++x) inB[r][x] = xch[(r * XR + 4 + x) * NCOL + colLW1];
-      // lane L-1 = (i, a-1) hands its values over in registers: one DPP wave shift,
-      // and the sentinel where a-1 leaves the band
+      // lane L-1 = (i, a-1) hands its values over in registers: one DPP wave shift fused with a min
+      // against the lane's cap (the sentinel where a-1 leaves the band, INT_MAX elsewhere).  One asm
+      // block per band column: the compiler's own DPP folding gives up once the consumers are sunk
+      // behind the store branches.  s_nop 1 = the two wait states a DPP read needs after a VALU write
+      // of its source (the hazard recogniser does not look inside asm); lane 0 reads out of range -> 0
+      // with bound_ctrl, it is an a_first lane anyway.  H2[.][M] (x = 2..4) of the last band column has
+      // no consumer: offset (0,0,M) from there would leave the band.
+      if (BIALIGN_OPT & 1) {
+        if (r + 1 < W) {
+          asm("s_nop 1\n\t"
+              "v_min_i32_dpp %0, %8, %16 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+              "v_min_i32_dpp %1, %9, %16 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+              "v_min_i32_dpp %2, %10, %16 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+              "v_min_i32_dpp %3, %11, %16 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+              "v_min_i32_dpp %4, %12, %16 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+              "v_min_i32_dpp %5, %13, %16 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+              "v_min_i32_dpp %6, %14, %16 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+              "v_min_i32_dpp %7, %15, %16 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+              : "=&v"(inC[r][0]), "=&v"(inC[r][1]), "=&v"(inC[r][2]), "=&v"(inC[r][3]), "=&v"(inC[r][4]),
+                "=&v"(inC[r][5]), "=&v"(inC[r][6]), "=&v"(inC[r][7])
+              : "v"(pubC[r][0]), "v"(pubC[r][1]), "v"(pubC[r][2]), "v"(pubC[r][3]), "v"(pubC[r][4]),
+                "v"(pubC[r][5]), "v"(pubC[r][6]), "v"(pubC[r][7]), "v"(lane_cap));
+        } else {
+          asm("s_nop 1\n\t"
+              "v_min_i32_dpp %0, %5, %10 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+              "v_min_i32_dpp %1, %6, %10 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+              "v_min_i32_dpp %2, %7, %10 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+              "v_min_i32_dpp %3, %8, %10 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+              "v_min_i32_dpp %4, %9, %10 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+              : "=&v"(inC[r][0]), "=&v"(inC[r][1]), "=&v"(inC[r][5]), "=&v"(inC[r][6]), "=&v"(inC[r][7])
+              : "v"(pubC[r][0]), "v"(pubC[r][1]), "v"(pubC[r][5]), "v"(pubC[r][6]), "v"(pubC[r][7]), "v"(lane_cap));
+          inC[r][2] = inC[r][3] = inC[r][4] = SENT;
+        }
+      } else {
 #pragma unroll
-      for (int x = 0; x < 8; ++x) {
-        // (lane 0 reads out of range -> 0 with bound_ctrl; it is an a_first lane anyway)
-        const int nb = __builtin_amdgcn_mov_dpp(pubC[r][x], 0x138 /* wave_shr:1 */, 0xf, 0xf, true);
-        inC[r][x] = a_first ? SENT : nb;
+        for (int x = 0; x < 8; ++x) {
+          const int nb = __builtin_amdgcn_mov_dpp(pubC[r][x], 0x138 /* wave_shr:1 */, 0xf, 0xf, true);
+          inC[r][x] = a_first ? SENT : nb;
+        }
       }
     };
     read_rows(0);
@@ -589,7 +626,7 @@ __global__ void __launch_bounds__(64 * TW) fill_affine_kernel(const DeviceBatch 
       const int mu2v = mu2[bb];
       const int c_MM = mu1 + mu2v, c_gM = mu2v + gD, c2M = mu2v + dd;
 
-      int Tv[9];
+      auto cases = [&](int (&Tv)[9]) __attribute__((always_inline)) {
 #pragma unroll
       for (int hU = 0; hU < 3; ++hU) {
 #pragma unroll
@@ -635,10 +672,28 @@ __global__ void __launch_bounds__(64 * TW) fill_affine_kernel(const DeviceBatch 
         }
       }
 
+      };
       // finalise: ghost rows take the stored layers; "no valid case" -> -2^30
       // (pyx:299-303); points outside the lattice carry the sentinel.
       int M[9];
-      if (INTERIOR) {
+      if (INTERIOR && (BIALIGN_OPT & 2)) {
+        // ghost lanes keep what the ring delivered; the others compute in place under the
+        // execution mask (no per-value select)
+#pragma unroll
+        for (int q = 0; q < 9; ++q) M[q] = ghostM[bb * 9 + q];
+        if (!ghost) {
+          int Tv[9];
+          cases(Tv);
+#pragma unroll
+          for (int q = 0; q < 9; ++q) {
+            int tv = Tv[q];
+            if (can_be_empty<W>(q / 3, q % 3, bb)) tv = tv < THRESH ? NEG : tv;
+            M[q] = tv;
+          }
+        }
+      } else if (INTERIOR) {
+        int Tv[9];
+        cases(Tv);
 #pragma unroll
         for (int q = 0; q < 9; ++q) {
           int tv = ghost ? ghostM[bb * 9 + q] : Tv[q];
@@ -646,6 +701,8 @@ __global__ void __launch_bounds__(64 * TW) fill_affine_kernel(const DeviceBatch 
           M[q] = tv;
         }
       } else {
+        int Tv[9];
+        cases(Tv);
         const int low = act ? NEG : SENT;
 #pragma unroll
         for (int q = 0; q < 9; ++q) {
