@@ -64,6 +64,8 @@ SYMBOLS = [
     ("bialign_engine_create", ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]),
     ("bialign_engine_destroy", None, [ctypes.c_void_p]),
     ("bialign_engine_trim", ctypes.c_int, [ctypes.c_void_p]),
+    ("bialign_engine_reserve", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int,
+                                              ctypes.POINTER(ctypes.c_double)]),
     ("bialign_batch_create", ctypes.c_int,
      [ctypes.c_void_p, ctypes.POINTER(Params), ctypes.POINTER(Scoring), ctypes.POINTER(Pairs),
       ctypes.c_int64, ctypes.POINTER(ctypes.c_void_p)]),

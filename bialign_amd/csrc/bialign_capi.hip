@@ -451,8 +451,18 @@ int bialign_batch_create(bialign_engine* eng, const bialign_params* prm, const b
     eng->layer_cache.release();
     HIP_TRY(b->d_layers.alloc(layer_dw));
   }
-  if (getenv("BIALIGN_DEBUG"))
-    fprintf(stderr, "[bialign] layers %p (%.1f GiB)\n", (void*)b->d_layers.p, b->max_chunk_dwords * 4.0 / (1 << 30));
+  if (getenv("BIALIGN_DEBUG")) {  // placement study: address and plain streaming-write rate of the layer buffer
+    float ms = 0;
+    for (int rep = 0; rep < 2; ++rep) {
+      HIP_TRY(hipEventRecord(eng->ev[0], st));
+      HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)b->d_layers.p, 0, layer_dw, st));
+      HIP_TRY(hipEventRecord(eng->ev[1], st));
+      HIP_TRY(hipEventSynchronize(eng->ev[1]));
+      HIP_TRY(hipEventElapsedTime(&ms, eng->ev[0], eng->ev[1]));
+    }
+    fprintf(stderr, "[bialign] layers %p (%.1f GiB) memset %.0f GB/s\n", (void*)b->d_layers.p,
+            layer_dw * 4.0 / (1 << 30), layer_dw * 4.0 / ms / 1e6);
+  }
   HIP_TRY(b->d_scores.alloc(pr->npairs));
   if (b->lean_trace) HIP_TRY(b->d_tstate.alloc(pr->npairs));
   HIP_TRY(b->d_tlen.alloc(pr->npairs));
@@ -476,6 +486,53 @@ void bialign_batch_destroy(bialign_batch* b) {
     eng->layer_cache.swap(b->d_layers);  // keep the larger buffer for the next batch
   }
   delete b;
+}
+
+// streaming-write rate of a buffer in GB/s (second of two memset passes)
+static int probe_write_rate(bialign_engine* e, int32_t* p, size_t dwords, double* gbps) {
+  float ms = 0;
+  for (int rep = 0; rep < 2; ++rep) {
+    HIP_TRY(hipEventRecord(e->ev[0], e->stream));
+    HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)p, 0, dwords, e->stream));
+    HIP_TRY(hipEventRecord(e->ev[1], e->stream));
+    HIP_TRY(hipEventSynchronize(e->ev[1]));
+    HIP_TRY(hipEventElapsedTime(&ms, e->ev[0], e->ev[1]));
+  }
+  *gbps = dwords * 4.0 / (ms * 1e6);
+  return BIALIGN_OK;
+}
+
+int bialign_engine_reserve(bialign_engine* e, int64_t bytes, int tries, double* rate_gbps) {
+  if (!e || bytes <= 0) return fail(BIALIGN_E_INVALID, "bad argument");
+  HIP_TRY(hipSetDevice(e->device));
+  const size_t dwords = ((size_t)bytes + 3) / 4;
+  DevBuf<int32_t> best;
+  double best_rate = 0;
+  if (e->layer_cache.n >= dwords) {  // what is cached is the first candidate
+    best.swap(e->layer_cache);
+  } else {
+    e->layer_cache.release();
+    HIP_TRY(best.alloc(dwords));
+  }
+  int rc = probe_write_rate(e, best.p, dwords, &best_rate);
+  for (int t = 1; t < tries && rc == BIALIGN_OK; ++t) {
+    size_t free_b = 0, total_b = 0;
+    HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+    if (free_b < (size_t)(dwords * 4 * 1.05)) break;  // no room for a second candidate next to the held one
+    DevBuf<int32_t> cand;
+    if (cand.alloc(dwords) != hipSuccess) { (void)hipGetLastError(); break; }
+    double rate = 0;
+    rc = probe_write_rate(e, cand.p, dwords, &rate);
+    if (rc == BIALIGN_OK && rate > best_rate * 1.005) {  // keep the better one; the other goes back
+      best.swap(cand);
+      best_rate = rate;
+    }
+  }
+  if (rc == BIALIGN_OK) {
+    e->layer_cache.swap(best);
+    if (rate_gbps) *rate_gbps = best_rate;
+  }
+  return rc;
 }
 
 int bialign_engine_trim(bialign_engine* e) {

@@ -35,6 +35,13 @@ class Engine:
         check(lib.bialign_engine_create(int(device), ctypes.byref(self._h)))
         self.device = int(device)
 
+    def reserve(self, nbytes, tries=4):
+        """Pre-allocate the layer buffer kept between batches and pick the best-placed of up to
+        ``tries`` candidate allocations (bialign_engine_reserve); returns its probe rate in GB/s."""
+        rate = ctypes.c_double()
+        check(lib.bialign_engine_reserve(self._h, int(nbytes), int(tries), ctypes.byref(rate)))
+        return rate.value
+
     def trim(self):
         """Release the layer buffer the engine keeps between batches (tens of GB after a large batch)."""
         check(lib.bialign_engine_trim(self._h))

@@ -142,6 +142,14 @@ int bialign_engine_create(int device, bialign_engine** out);
 void bialign_engine_destroy(bialign_engine* eng);
 /* Give the cached layer buffer back to the device (e.g. before another library needs the HBM). */
 int bialign_engine_trim(bialign_engine* eng);
+/* Pre-allocate the cached layer buffer (bytes) and choose WHERE it lies: on MI355X the physical
+ * region a large allocation lands in decides 10-20 % of the sweep's store rate, and a plain
+ * streaming write over the buffer predicts it (profiles/r01e_placement).  Up to `tries` candidate
+ * allocations are probed (two memset passes each); the fastest is kept for all later batches of
+ * this engine.  For long-running users: costs `tries` large allocations once.  Needs twice the
+ * buffer in free HBM while it runs, otherwise it just allocates.  *rate_gbps (may be NULL)
+ * receives the kept buffer's probe rate. */
+int bialign_engine_reserve(bialign_engine* eng, int64_t bytes, int tries, double* rate_gbps);
 
 /* Upload a batch and allocate its DP storage: BiAligner.__init__ (pyx:179-197)
  * for the part that reaches the DP, plus AffineDPMatrices / SparseMatrix4D

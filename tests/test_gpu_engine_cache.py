@@ -53,3 +53,17 @@ def test_engine_close_closes_its_batches():
     eng.close()
     assert b._h is None
     b.close()  # idempotent
+
+
+def test_reserve_picks_a_buffer_and_batches_use_it():
+    from bialign_amd.engine import Engine
+    eng = Engine(0)
+    rate = eng.reserve(96 << 20, tries=3)
+    assert rate > 100.0                      # GB/s of the kept candidate's probe
+    pairs = [synth.protein_pair(70 + t, 120, 110) for t in range(4)]
+    b, r = solve(eng, pairs, dict(synth.PROTEIN_PARAMS))
+    b2, r2 = solve(eng, pairs, dict(synth.PROTEIN_PARAMS))   # second live batch: own allocation
+    assert r == r2
+    b.close(); b2.close()
+    assert eng.reserve(16 << 20, tries=1) > 0   # smaller request: the cached buffer is the candidate
+    eng.close()
