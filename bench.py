@@ -92,7 +92,7 @@ def main():
     batch = make_batch(pairs, params, engine=engine)  # inputs now resident in HBM
     info = batch.info
     placement = {"reserve_tries": 1, "probe_gbps": None}
-    if args.reserve_tries > 1:
+    if args.reserve_tries > 1 and not rehearse:  # (rehearsal ranks share one GPU's memory)
         # Setup, untimed: where the 83 GiB layer buffer lands physically decides 10-20 % of the fill time
         # (profiles/r01e_placement); a long-running engine picks its buffer once (Engine.reserve) and keeps it.
         batch.close()
