@@ -8,7 +8,7 @@ E = lambda k, d: int(os.environ.get(k, d))
 pairs = synth.rna_batch(E("AB_PAIRS", 64), E("AB_LEN", 2000))
 params = dict(synth.RNA_PARAMS, max_shift=E("AB_S", 2))
 for cycle in range(E("AB_CYCLES", 3)):
-    b = make_batch(pairs, params)
+    b = make_batch(pairs, params, score_only=bool(E("AB_LEAN", 0)), lean_trace=bool(E("AB_LEANTRACE", 0)))
     ts = []
     for _ in range(3):
         b.run(); ts.append(b.timing()["fill_ms"])
@@ -21,4 +21,4 @@ for cycle in range(E("AB_CYCLES", 3)):
     default_engine().trim()
     if cycle == 0:
         import hashlib
-        print("   scores sha", hashlib.sha1(b_scores.tobytes()).hexdigest()[:12], flush=True)
+        print("   scores sha", hashlib.sha1(b_scores.tobytes()).hexdigest()[:12], f"traceback {t['traceback_ms']:.1f} ms", flush=True)
