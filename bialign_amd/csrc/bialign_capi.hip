@@ -311,8 +311,8 @@ int bialign_batch_create(bialign_engine* eng, const bialign_params* prm, const b
   b->dense = pr->mu2_dense != nullptr;
   b->lean_trace = (prm->flags & BIALIGN_BATCH_LEAN_TRACE) != 0;
   b->lean = b->lean_trace || (prm->flags & BIALIGN_BATCH_SCORE_ONLY) != 0;
-  if (b->lean_trace && (!b->affine || b->dense))
-    return fail(BIALIGN_E_UNSUPPORTED, "BIALIGN_BATCH_LEAN_TRACE needs the affine recurrence in LOOKUP form");
+  if (b->lean_trace && !b->affine)
+    return fail(BIALIGN_E_UNSUPPORTED, "BIALIGN_BATCH_LEAN_TRACE needs the affine recurrence");
   if (b->dense && !pr->mu2_off) return fail(BIALIGN_E_INVALID, "mu2_dense given without mu2_off");
   if (!b->dense && (!pr->cls_a || !pr->cls_b)) return fail(BIALIGN_E_INVALID, "cls_a / cls_b are NULL (LOOKUP form)");
   const int S = b->S, W = 2 * S + 1;
@@ -395,8 +395,8 @@ int bialign_batch_create(bialign_engine* eng, const bialign_params* prm, const b
   if (b->lean_trace) pick_resw_k();
   size_pairs();
   // A pair whose full layers exceed the budget is served from reduced storage instead of failing
-  // (memory-lean traceback, ~1.3x the time) where that mode exists: affine recurrence, LOOKUP form.
-  if (!b->lean && b->affine && !b->dense &&
+  // (memory-lean traceback, ~1.3x the time) where that mode exists: the affine recurrence.
+  if (!b->lean && b->affine &&
       *std::max_element(pair_dwords.begin(), pair_dwords.end()) > budget_dw) {
     b->lean = b->lean_trace = true;
     pick_resw_k();

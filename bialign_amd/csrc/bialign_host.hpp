@@ -211,6 +211,9 @@ int launch_resweep_affine(bialign_batch* b, const DeviceBatch& v, int first, int
     HIP_TRY(hipGetLastError());
     return BIALIGN_OK;
   };
+  if (b->dense)
+    return b->prm.gap_opening_cost > 0 ? go(fill_affine_kernel<S, false, 1, false, true, false, true>)
+                                       : go(fill_affine_kernel<S, true, 1, false, true, false, true>);
   return b->prm.gap_opening_cost > 0 ? go(fill_affine_kernel<S, false, 1, false, false, false, true>)
                                      : go(fill_affine_kernel<S, true, 1, false, false, false, true>);
 }

@@ -341,7 +341,7 @@ __device__ __forceinline__ void store_chunk(int32_t* p, v4i v) {
 template <int S, bool BETA_NONPOS, int TW, bool XCU, bool DENSE = false, bool LEAN = false, bool RESW = false>
 __global__ void __launch_bounds__(64 * TW) fill_affine_kernel(const DeviceBatch A) {
   static_assert(!XCU || TW == 1, "cross-CU teams are built from one-wave workgroups");
-  static_assert(!RESW || (TW == 1 && !XCU && !LEAN && !DENSE), "strip re-sweeps: one wave, LOOKUP form, full records");
+  static_assert(!RESW || (TW == 1 && !XCU && !LEAN), "strip re-sweeps: one wave, full records");
   using G_ = Geo<S>;
   using R_ = Rec<S, 9, LEAN>;
   constexpr int W = G_::W, R = G_::R, RR = G_::RR, PADB = G_::PADB;
@@ -498,7 +498,7 @@ __global__ void __launch_bounds__(64 * TW) fill_affine_kernel(const DeviceBatch 
     // blk_q/blk_rem describe h0
     wait_partner(h0 + GF::BLK - 1);
     GF::issue(lay, h0 + Qbase * P, blk_q, blk_rem, P, T, w, GOFF, rec_last, L, ring_lds + half * GF::SLOTS * 16);
-    if (DENSE) MF::issue(mu2tab, n, m, P, jj0, strip, T, w, il, aa, mu2_lds + half * MF::BLK * 256);
+    if (DENSE) MF::issue(mu2tab, n, m, P, jj0, Qbase + strip, T, w, il, aa, mu2_lds + half * MF::BLK * 256);
     blk_rem += GF::BLK;
     if (blk_rem >= P) { blk_rem -= P; ++blk_q; }
   };

@@ -125,3 +125,14 @@ def test_one_pair_of_length_twenty_thousand():
     assert lean[3]["hbm_layer_bytes"] * 8 < full[3]["hbm_layer_bytes"]
     print(f"full: fill {full[4]['fill_ms']:.0f} tb {full[4]['traceback_ms']:.0f} ms, {full[3]['hbm_layer_bytes'] / 2**30:.1f} GiB | "
           f"lean: fill {lean[4]['fill_ms']:.0f} tb {lean[4]['traceback_ms']:.0f} ms, {lean[3]['hbm_layer_bytes'] / 2**30:.1f} GiB")
+
+
+@pytest.mark.parametrize("k", ["1", "4"])
+def test_dense_mu2_form(k, monkeypatch):
+    monkeypatch.setenv("BIALIGN_RESW_K", k)
+    rng = np.random.default_rng(9)
+    shapes = [(130, 75), (75, 130), (40, 50), (300, 280), (1, 1), (250, 30)]
+    pairs = [synth.protein_pair(1800 + t, n, m) for t, (n, m) in enumerate(shapes)]
+    tabs = [rng.integers(-300, 900, size=(n, m)).astype(np.int32) for n, m in shapes]
+    for s in (0, 1, 2, 3):
+        same(pairs, dict(synth.PROTEIN_PARAMS, max_shift=s), mu2_dense=tabs)
