@@ -159,23 +159,17 @@ int lean_traceback_rounds(bialign_batch* b, const DeviceBatch& v, int first, int
   rounds = (rounds + b->resw_k - 1) / b->resw_k;
   for (int r = 0; r < rounds; ++r) {
     int rc = BIALIGN_E_UNSUPPORTED;
+#define BIALIGN_ROUND(S)                                                                              \
+  case S:                                                                                             \
+    rc = b->affine ? launch_resweep_affine<S>(b, v, first, count) : launch_resweep_linear<S>(b, v, first, count);          \
+    if (rc == BIALIGN_OK)                                                                             \
+      rc = b->affine ? launch_traceback_affine_strip<S>(b, v, first, count)                           \
+                     : launch_traceback_linear_strip<S>(b, v, first, count);                          \
+    break;
     switch (b->S) {
-      case 0: rc = launch_resweep_affine<0>(b, v, first, count); break;
-      case 1: rc = launch_resweep_affine<1>(b, v, first, count); break;
-      case 2: rc = launch_resweep_affine<2>(b, v, first, count); break;
-      case 3: rc = launch_resweep_affine<3>(b, v, first, count); break;
-      case 4: rc = launch_resweep_affine<4>(b, v, first, count); break;
-      case 5: rc = launch_resweep_affine<5>(b, v, first, count); break;
+      BIALIGN_ROUND(0) BIALIGN_ROUND(1) BIALIGN_ROUND(2) BIALIGN_ROUND(3) BIALIGN_ROUND(4) BIALIGN_ROUND(5)
     }
-    if (rc) return rc;
-    switch (b->S) {
-      case 0: rc = launch_traceback_affine_strip<0>(b, v, first, count); break;
-      case 1: rc = launch_traceback_affine_strip<1>(b, v, first, count); break;
-      case 2: rc = launch_traceback_affine_strip<2>(b, v, first, count); break;
-      case 3: rc = launch_traceback_affine_strip<3>(b, v, first, count); break;
-      case 4: rc = launch_traceback_affine_strip<4>(b, v, first, count); break;
-      case 5: rc = launch_traceback_affine_strip<5>(b, v, first, count); break;
-    }
+#undef BIALIGN_ROUND
     if (rc) return rc;
   }
   return BIALIGN_OK;
@@ -311,8 +305,6 @@ int bialign_batch_create(bialign_engine* eng, const bialign_params* prm, const b
   b->dense = pr->mu2_dense != nullptr;
   b->lean_trace = (prm->flags & BIALIGN_BATCH_LEAN_TRACE) != 0;
   b->lean = b->lean_trace || (prm->flags & BIALIGN_BATCH_SCORE_ONLY) != 0;
-  if (b->lean_trace && !b->affine)
-    return fail(BIALIGN_E_UNSUPPORTED, "BIALIGN_BATCH_LEAN_TRACE needs the affine recurrence");
   if (b->dense && !pr->mu2_off) return fail(BIALIGN_E_INVALID, "mu2_dense given without mu2_off");
   if (!b->dense && (!pr->cls_a || !pr->cls_b)) return fail(BIALIGN_E_INVALID, "cls_a / cls_b are NULL (LOOKUP form)");
   const int S = b->S, W = 2 * S + 1;
@@ -395,8 +387,8 @@ int bialign_batch_create(bialign_engine* eng, const bialign_params* prm, const b
   if (b->lean_trace) pick_resw_k();
   size_pairs();
   // A pair whose full layers exceed the budget is served from reduced storage instead of failing
-  // (memory-lean traceback, ~1.3x the time) where that mode exists: the affine recurrence.
-  if (!b->lean && b->affine &&
+  // (memory-lean traceback, ~1.3x the time).
+  if (!b->lean &&
       *std::max_element(pair_dwords.begin(), pair_dwords.end()) > budget_dw) {
     b->lean = b->lean_trace = true;
     pick_resw_k();

@@ -284,6 +284,35 @@ int launch_fill_linear(bialign_batch* b, const DeviceBatch& v, int first, int co
 }
 
 template <int S>
+int launch_resweep_linear(bialign_batch* b, const DeviceBatch& v, int first, int count) {
+  DeviceBatch w = v;
+  w.order = v.order + first;
+  const size_t lds = b->lds_base + b->lds_per_wave;
+  auto go = [&](auto kern) -> int {
+    if (lds > 64 * 1024)
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3(count * b->resw_k), dim3(64), lds, b->eng->stream, w);
+    HIP_TRY(hipGetLastError());
+    return BIALIGN_OK;
+  };
+  return b->dense ? go(fill_linear_kernel<S, 1, true, false, true>) : go(fill_linear_kernel<S, 1, false, false, true>);
+}
+
+template <int S>
+int launch_traceback_linear_strip(const bialign_batch* b, const DeviceBatch& v, int first, int count) {
+  DeviceBatch w = v;
+  w.order = v.order + first;
+  auto kern = traceback_linear_kernel<S, true, true>;
+  if (b->lds_trace > 64 * 1024)
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_trace));
+  hipLaunchKernelGGL(kern, dim3(count), dim3(64), b->lds_trace, b->eng->stream, w, count);
+  HIP_TRY(hipGetLastError());
+  return BIALIGN_OK;
+}
+
+template <int S>
 int launch_traceback_linear(const bialign_batch* b, const DeviceBatch& v, int first, int count,
                             bool do_trace) {
   DeviceBatch w = v;
@@ -316,6 +345,8 @@ int launch_dump(const bialign_batch* b, const DeviceBatch& v, int pid, int32_t* 
   X template int launch_traceback_affine<S>(const bialign_batch*, const DeviceBatch&, int, int, bool);  \
   X template int launch_traceback_affine_strip<S>(const bialign_batch*, const DeviceBatch&, int, int);  \
   X template int launch_traceback_linear<S>(const bialign_batch*, const DeviceBatch&, int, int, bool);  \
+  X template int launch_resweep_linear<S>(bialign_batch*, const DeviceBatch&, int, int);                \
+  X template int launch_traceback_linear_strip<S>(const bialign_batch*, const DeviceBatch&, int, int);  \
   X template int launch_dump<S, 9>(const bialign_batch*, const DeviceBatch&, int, int32_t*);            \
   X template int launch_dump<S, 1>(const bialign_batch*, const DeviceBatch&, int, int32_t*);
 #define BIALIGN_FOR_EACH_S(M, X) M(0, X) M(1, X) M(2, X) M(3, X) M(4, X) M(5, X)

@@ -1034,7 +1034,7 @@ __global__ void __launch_bounds__(64) traceback_affine_kernel(const DeviceBatch 
 // later and kept in registers for the cases that need them 2 or 3 steps later
 // (age of offset o = o0 + o1 + o2).
 // ---------------------------------------------------------------------------
-template <int S, int TW, bool DENSE = false, bool LEAN = false>
+template <int S, int TW, bool DENSE = false, bool LEAN = false, bool RESW = false>
 __global__ void __launch_bounds__(64 * TW) fill_linear_kernel(const DeviceBatch A) {
   using G_ = Geo<S>;
   using R_ = Rec<S, 1, LEAN>;
@@ -1043,9 +1043,20 @@ __global__ void __launch_bounds__(64 * TW) fill_linear_kernel(const DeviceBatch 
   extern __shared__ __align__(16) int32_t smem[];
 
   constexpr int T = TW;  // team = the workgroup's waves (see fill_affine_kernel)
-  const int pid = A.order[blockIdx.x];
+  static_assert(!RESW || (TW == 1 && !LEAN), "strip re-sweeps (see fill_affine_kernel): one wave, full records");
+  const int pslot = RESW ? blockIdx.x / A.resw_k : blockIdx.x;
+  const int pid = A.order[pslot];
   const PairDesc pd = A.pairs[pid];
   const int n = pd.n, m = pd.m, P = pd.P;
+  int Qbase = 0, jlim = m, kk = 0;  // RESW: the strip to sweep, the last column the walk can still reach
+  if (RESW) {
+    const TraceState ts0 = A.tstate[pid];
+    if (ts0.done) return;
+    kk = blockIdx.x - pslot * A.resw_k;
+    Qbase = (ts0.started ? ts0.strip : pd.NS - 1) - kk;
+    if (Qbase < 0) return;
+    jlim = (ts0.started && kk == 0) ? ts0.j : m;
+  }
   const int L = threadIdx.x & 63;
   const int w = TW == 1 ? 0 : __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int il = L / W, aa = L - il * W;
@@ -1055,7 +1066,7 @@ __global__ void __launch_bounds__(64 * TW) fill_linear_kernel(const DeviceBatch 
   const int k1 = A.k1, k2 = A.k2;
   const int gD = gamma + delta, gg = 2 * gamma;
 
-  using GF = GhostFeed<S, 1, LEAN>;
+  using GF = GhostFeed<S, 1, LEAN || RESW>;
   using MF = Mu2Feed<S>;
   constexpr int PERW = GF::RING_DW + NV * NCOL + (DENSE ? MF::RING_DW : 0);
   v4i* ring = reinterpret_cast<v4i*>(smem + w * GF::RING_DW);
@@ -1090,18 +1101,19 @@ __global__ void __launch_bounds__(64 * TW) fill_linear_kernel(const DeviceBatch 
   const int colLW1 = (live && il >= 1 && aa < W - 1) ? L - W + 1 : 64;
   const int colL1 = (live && il >= 1 && aa > 0) ? L - 1 : 64;
   const int GOFF = P - 2 * (R - 1);
-  int32_t* const lay = A.layers + pd.layer_off;
+  int32_t* const lay = A.layers + pd.layer_off;  // records the ghost feed replays
+  int32_t* const sto = RESW ? A.scratch + pd.scratch_off + (int64_t)kk * (m + G_::MAXOFF + 1) * RECDW : lay;
 
   const int rec_last = pd.G - 1;
-  const int NSw = (pd.NS - w + T - 1) / T;  // this wave's strips: w, w+T, ...
-  const int H = NSw > 0 ? (NSw - 1) * P + m + G_::MAXOFF + 1 : 0;
+  const int NSw = RESW ? 1 : (pd.NS - w + T - 1) / T;  // this wave's strips: w, w+T, ...
+  const int H = NSw > 0 ? (NSw - 1) * P + (RESW ? jlim : m) + G_::MAXOFF + 1 : 0;
   int jj = -(2 * il + aa);
   int strip = 0;         // local strip index q; lattice strip = q*T + w
   int rec_base = w * P;  // record of local step h for this lane = h + rec_base
   int i = 0, s1row = 0, s2row = 0;
   bool act_row = false;
   auto set_row = [&](int q) {
-    i = (q * T + w) * RR + il - 1;
+    i = (Qbase + q * T + w) * RR + il - 1;
     const int k = i + aa - S;
     act_row = live && i >= 0 && i <= n && k >= 0 && k <= n;
     s1row = (i >= 1 && i <= n) ? sa[i - 1] * k1 : 0;
@@ -1144,8 +1156,8 @@ __global__ void __launch_bounds__(64 * TW) fill_linear_kernel(const DeviceBatch 
   for (int bb = 0; bb < W; ++bb) mu2w[bb] = 0;
   auto prefetch_block = [&](int h0, int half, int jj0) __attribute__((always_inline)) {
     wait_partner(h0 + GF::BLK - 1);
-    GF::issue(lay, h0, blk_q, blk_rem, P, T, w, GOFF, rec_last, L, ring_lds + half * GF::SLOTS * 16);
-    if (DENSE) MF::issue(mu2tab, n, m, P, jj0, strip, T, w, il, aa, mu2_lds + half * MF::BLK * 256);
+    GF::issue(lay, h0 + Qbase * P, blk_q, blk_rem, P, T, w, GOFF, rec_last, L, ring_lds + half * GF::SLOTS * 16);
+    if (DENSE) MF::issue(mu2tab, n, m, P, jj0, Qbase + strip, T, w, il, aa, mu2_lds + half * MF::BLK * 256);
     blk_rem += GF::BLK;
     if (blk_rem >= P) { blk_rem -= P; ++blk_q; }
   };
@@ -1234,7 +1246,7 @@ __global__ void __launch_bounds__(64 * TW) fill_linear_kernel(const DeviceBatch 
     if (__builtin_amdgcn_ballot_w64(do_store) != 0) vm_younger += GF::STORES_PER_STEP;
     if (do_store) {
       const int slot = LEAN ? aa : L - W;
-      int32_t* dst = lay + (int64_t)rec * RECDW;
+      int32_t* dst = sto + (int64_t)rec * RECDW;
 #pragma unroll
       for (int c = 0; c < NCH4; ++c) {
         v4i v;
@@ -1245,7 +1257,7 @@ __global__ void __launch_bounds__(64 * TW) fill_linear_kernel(const DeviceBatch 
       for (int t = 0; t < TAIL; ++t) dst[NCH4 * R_::CH + slot * TAIL + t] = outv[4 * NCH4 + t];
     }
     ++jj;
-    if (jj == P) {
+    if (!RESW && jj == P) {
       jj = 0;
       ++strip;
       rec_base += (T - 1) * P;
@@ -1261,7 +1273,7 @@ __global__ void __launch_bounds__(64 * TW) fill_linear_kernel(const DeviceBatch 
 // Non-affine traceback (pyx:513-531): the first case, in generator order, that is
 // guard-valid and reproduces the cell; stops when none does (the origin).  One wave
 // per pair, lane c < 13 = case c; "first" = wave-min over the matching lane ids.
-template <int S, bool DO_TRACE>
+template <int S, bool DO_TRACE, bool STRIP = false>  // STRIP: see traceback_affine_kernel
 __global__ void __launch_bounds__(64) traceback_linear_kernel(const DeviceBatch A, int npairs) {
   const int pid = A.order[blockIdx.x];
   const PairDesc pd = A.pairs[pid];
@@ -1270,9 +1282,25 @@ __global__ void __launch_bounds__(64) traceback_linear_kernel(const DeviceBatch 
   const int32_t* lay = A.layers;
   const int c = threadIdx.x;
   constexpr int BIG = 0x7fffffff;
+  constexpr int W = 2 * S + 1, RR = Geo<S>::RR;
   extern __shared__ __align__(16) int32_t smem[];
-  int cur = lay[cell_dword<S, 1>(pd, n, m, S, S, 0)];
-  if (c == 0) A.scores[pid] = cur;  // pyx:471
+  TraceState ts{};
+  if (STRIP) {
+    ts = A.tstate[pid];
+    if (ts.done) return;
+  }
+  const int Q = STRIP ? (ts.started ? ts.strip : pd.NS - 1) : 0;
+  const int Qlo = STRIP ? max(Q - A.resw_k + 1, 0) : 0;
+  const int64_t sstride = (int64_t)(m + Geo<S>::MAXOFF + 1) * Rec<S, 1>::RECDW;
+  auto cell = [&](int pi, int pj, int a, int b) -> int {
+    if (!STRIP) return lay[cell_dword<S, 1>(pd, pi, pj, a, b, 0)];
+    const int sp = pi / RR, ilp = pi - sp * RR + 1;
+    if (sp >= Qlo)
+      return A.scratch[pd.scratch_off + (Q - sp) * sstride + Rec<S, 1>::dword(pj + 2 * ilp + a, (ilp - 1) * W + a, b)];
+    return lay[pd.layer_off + Rec<S, 1, true>::dword((int64_t)sp * pd.P + pj + 2 * ilp + a, a, b)];
+  };
+  int cur = (STRIP && ts.started) ? ts.cur : cell(n, m, S, S);
+  if (c == 0 && !(STRIP && ts.started)) A.scores[pid] = cur;  // pyx:471
   if (!DO_TRACE) return;
   const TraceInputs in = stage_trace_inputs(A, pd, smem);
   const uint8_t *sa = in.sa, *ca = in.ca, *sb = in.sb, *cb = in.cb;
@@ -1291,7 +1319,10 @@ __global__ void __launch_bounds__(64) traceback_linear_kernel(const DeviceBatch 
 
   uint8_t* out = A.trace + pd.trace_off;
   int i = n, j = m, k = n, l = m, len = 0;
+  if (STRIP && ts.started) { i = ts.i; j = ts.j; k = ts.k; l = ts.l; len = ts.len; }
+  bool finished = true;
   while (true) {
+    if (STRIP && i < Qlo * RR) { finished = false; break; }
     const int mu1 = (i >= 1 && j >= 1) ? in.s1[sa[i - 1] * A.k1 + sb[j - 1]] : 0;
     const int mu2 = (k >= 1 && l >= 1)
                         ? (A.mu2_dense ? A.mu2_dense[pd.mu2_off + (int64_t)(k - 1) * m + (l - 1)]
@@ -1300,7 +1331,7 @@ __global__ void __launch_bounds__(64) traceback_linear_kernel(const DeviceBatch 
     const int sc = kconst + (use1 ? mu1 : 0) + (use2 ? mu2 : 0);
     const int pi = i - o0, pj = j - o1, pk = k - o2, pl = l - o3;
     const bool ok = c < 13 && pi >= 0 && pj >= 0 && pk >= 0 && pl >= 0 && abs(pk - pi) <= S && abs(pl - pj) <= S;
-    const int ld = ok ? lay[cell_dword<S, 1>(pd, pi, pj, pk - pi + S, pl - pj + S, 0)] : 0;
+    const int ld = ok ? cell(pi, pj, pk - pi + S, pl - pj + S) : 0;
     const int key = (ok && ld + sc == cur) ? c : BIG;
     const int pick = __builtin_amdgcn_readfirstlane(wave_min16(key));
     if (pick == BIG) break;
@@ -1309,6 +1340,15 @@ __global__ void __launch_bounds__(64) traceback_linear_kernel(const DeviceBatch 
     if (c == 0 && len < pd.trace_cap) out[len] = (uint8_t)code;
     ++len;
     i -= (code >> 3) & 1; j -= (code >> 2) & 1; k -= (code >> 1) & 1; l -= code & 1;
+  }
+  if (STRIP && !finished) {
+    if (c == 0) {
+      TraceState nx{};
+      nx.i = i; nx.j = j; nx.k = k; nx.l = l; nx.cur = cur; nx.len = len;
+      nx.strip = Qlo - 1; nx.started = 1; nx.done = 0;
+      A.tstate[pid] = nx;
+    }
+    return;
   }
   if (len > pd.trace_cap) len = pd.trace_cap;
   __builtin_amdgcn_s_waitcnt(0);
@@ -1321,6 +1361,11 @@ __global__ void __launch_bounds__(64) traceback_linear_kernel(const DeviceBatch 
   if (c == 0) {
     A.trace_len[pid] = len;
     A.complete[pid] = 1;
+    if (STRIP) {
+      ts.done = 1;
+      ts.started = 1;
+      A.tstate[pid] = ts;
+    }
   }
 }
 

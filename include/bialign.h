@@ -59,7 +59,7 @@ extern "C" {
 /* LEAN_TRACE: full results (scores and traces) from the same reduced storage: after the lean sweep
  * the traceback re-sweeps one strip of lattice rows at a time into a small per-pair scratch area
  * and walks through it.  About a tenth of the HBM footprint of the default mode for ~1.3x the time:
- * for pairs whose layers would not fit otherwise.  Affine recurrence only. */
+ * for pairs whose layers would not fit otherwise. */
 #define BIALIGN_BATCH_LEAN_TRACE 2u
 
 typedef struct bialign_engine bialign_engine; /* one per (process, device) */

@@ -74,12 +74,40 @@ def test_chunked_and_ragged():
     assert lean[1] == full[1] and lean[2] == full[2]
 
 
+LIN = dict(gap_opening_cost=0, gap_cost=-200, shift_cost=-250)
+
+
+@pytest.mark.parametrize("k", ["1", "3", "32"])
+@pytest.mark.parametrize("s", [0, 1, 2, 3, 4, 5])
+def test_one_layer_recurrence(s, k, monkeypatch):
+    monkeypatch.setenv("BIALIGN_RESW_K", k)
+    rng = np.random.default_rng(60 + s)
+    shapes = [(int(rng.integers(1, 140)), int(rng.integers(1, 140))) for _ in range(14)] + \
+             [(1, 1), (64, 64), (63, 1), (1, 90), (400, 380), (30, 700), (700, 30)]
+    pairs = [synth.protein_pair(1900 + t, n, m) for t, (n, m) in enumerate(shapes)]
+    same(pairs, dict(synth.PROTEIN_PARAMS, max_shift=s, **LIN))
+
+
+def test_one_layer_dense_and_golden():
+    rng = np.random.default_rng(10)
+    shapes = [(130, 75), (75, 130), (300, 280)]
+    pairs = [synth.protein_pair(1950 + t, n, m) for t, (n, m) in enumerate(shapes)]
+    tabs = [rng.integers(-300, 900, size=(n, m)).astype(np.int32) for n, m in shapes]
+    same(pairs, dict(synth.PROTEIN_PARAMS, max_shift=2, **LIN), mu2_dense=tabs)
+    from bialign_amd.engine import trace_codes_to_columns
+    for rec in load_golden("medium_traces.json") + load_golden("known_answers.json"):
+        p = rec["params"]
+        if p["gap_opening_cost"] != 0 or p["max_shift"] > 5:
+            continue
+        got = run([(rec["seqA"], rec["seqB"], rec["strA"], rec["strB"])], p, lean_trace=True)
+        assert int(got[0][0]) == rec["score"]
+        assert trace_codes_to_columns(np.array(got[1][0], dtype=np.uint8)) == rec["trace"]
+
+
 def test_refusals():
     from bialign_amd.batch import make_batch
     from bialign_amd._lib import BialignError
     pair = synth.protein_pair(1, 30, 30)
-    with pytest.raises(BialignError):  # non-affine recurrence
-        make_batch([pair], dict(synth.PROTEIN_PARAMS, gap_opening_cost=0), lean_trace=True)
     b = make_batch([pair], dict(synth.PROTEIN_PARAMS), lean_trace=True)
     b.run()
     with pytest.raises(BialignError):
@@ -106,8 +134,13 @@ def test_engine_falls_back_to_lean_traceback_when_a_pair_exceeds_the_budget():
     assert lean[3]["storage"] == BATCH_LEAN_TRACE
     np.testing.assert_array_equal(lean[0], full[0])
     assert lean[1] == full[1] and lean[2] == full[2]
-    with pytest.raises(BialignError):   # the one-layer recurrence has no such mode: still an error
-        make_batch(pairs, dict(params, gap_opening_cost=0), hbm_budget_bytes=1 << 20)
+    lin = dict(params, **LIN)
+    full_l, lean_l = run(pairs, lin), run(pairs, lin, hbm_budget_bytes=2 << 20)   # one-layer: ~5.6 MB per pair
+    assert lean_l[3]["storage"] == BATCH_LEAN_TRACE
+    np.testing.assert_array_equal(lean_l[0], full_l[0])
+    assert lean_l[1] == full_l[1]
+    with pytest.raises(BialignError):   # not even the reduced storage of one pair fits: still an error
+        make_batch(pairs, params, hbm_budget_bytes=64 << 10)
 
 
 def test_single_long_pair_many_strips_per_round():
