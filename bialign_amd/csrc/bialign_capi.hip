@@ -36,11 +36,14 @@ TeamShape team_shape(const bialign_batch* b, int first, int count) {
   TeamShape ts;
   const int W = 2 * b->S + 1, R = 64 / W;
   const int lag = 2 * (R - 1) + 2 * ghost_blk(b->S) + 16;
-  int fit = 32;  // largest team the pairs of this launch allow
+  int fit_exact = 32;  // largest team the pairs of this launch allow: T*lag + 64 <= P (P >= 256), two strips per wave
   for (int t = first; t < first + count; ++t) {
     const PairDesc& d = b->pairs[b->order[t]];
-    while (fit > 1 && (d.P < std::max(256, fit * lag + 64) || d.NS < 2 * fit)) fit >>= 1;
+    const int by_period = d.P >= 256 ? (d.P - 64) / lag : 1;
+    fit_exact = std::max(1, std::min(fit_exact, std::min(by_period, d.NS / 2)));
   }
+  int fit = 1;  // in-workgroup teams come in powers of two (kernel template parameter)
+  while (fit * 2 <= fit_exact) fit *= 2;
   // the one-layer (non-affine) kernel is small in registers at every s
   int tw = std::min(fit, !b->affine ? 8 : (b->S <= 1 ? 8 : (b->S <= 3 ? 4 : 1)));
   while (tw > 1 && b->lds_base + (size_t)tw * b->lds_per_wave > 160 * 1024) tw >>= 1;
@@ -50,14 +53,13 @@ TeamShape team_shape(const bialign_batch* b, int first, int count) {
   const size_t by_regs = b->S <= 2 ? 8 : 4;
   const int resident = b->eng->num_cu * (int)std::min<size_t>(by_regs, (160 * 1024) / lds1);
   if (b->dense) tw = std::min(tw, 2);  // dense-mu2 kernels are instantiated for 1 and 2 waves
-  int gw = (b->affine && b->S <= 3 && !b->dense) ? fit : 1;  // cross-CU teams: affine LOOKUP kernels only
-  while (gw > 1 && (int64_t)count * gw > resident) gw >>= 1;
+  // cross-CU teams (affine LOOKUP kernels only) take any size: the team is a runtime value there
+  int gw = (b->affine && b->S <= 3 && !b->dense) ? fit_exact : 1;
+  gw = std::max(1, std::min(gw, resident / std::max(count, 1)));
 
   const char* e = getenv("BIALIGN_TEAM");  // experiments / tests: "N" in-workgroup, "xN" cross-CU
   if (e && e[0] == 'x') {
-    int want = atoi(e + 1), g = 1;
-    while (g * 2 <= want && g * 2 <= gw) g *= 2;
-    ts.gw = g;
+    ts.gw = std::max(1, std::min(atoi(e + 1), gw));
     return ts;
   }
   if (e) {
@@ -84,11 +86,12 @@ TeamShape team_shape(const bialign_batch* b, int first, int count) {
   int t = 1;
   while (t < tw && concurrent(t) * 100 < best * 95) t *= (skip2 && t == 1) ? 4 : 2;
   ts.tw = t;
-  // cross-CU: only when the chip would stay mostly empty and the team can be at least doubled
-  if (count * t <= 512 && gw >= 2 * t) {
-    int g = 1;
-    while (g * 2 <= gw && count * g * 2 <= 2048) g *= 2;
-    if (g >= 2 * t) { ts.tw = 1; ts.gw = g; }
+  // cross-CU: when the chip would stay mostly empty and the team can be at least doubled -- or, for
+  // a handful of pairs, not doubled but spread: eight waves on eight CUs beat eight waves sharing
+  // one CU's SIMDs two by two (one 928 x 933 pair: 7.6 vs 9.4 ms)
+  if (count * t <= 512) {
+    const int g = std::min(gw, std::max(1, 2048 / count));
+    if (g >= 2 * t || (t == 8 && g >= 8 && count * 8 <= b->eng->num_cu)) { ts.tw = 1; ts.gw = g; }
   }
   return ts;
 }
