@@ -472,12 +472,16 @@ __global__ void __launch_bounds__(64 * TW) fill_affine_kernel(const DeviceBatch 
     else
       prog_lds[w] = v;
   };
+  int seen_prog = -0x40000000;  // the partner's progress as last read
   auto wait_partner = [&](int h_last) __attribute__((always_inline)) {
     if ((!XCU && TW == 1) || T == 1 || team_failed || BIALIGN_EXP == 9) return;  // 9: timing experiment, no hand-off waits
     const int src = w == 0 ? T - 1 : w - 1;
     const int need = h_last + 2 * (R - 1) + 1 - (w == 0 ? P : 0);
+    // progress only grows: what was seen last time usually covers this block too, and a look at
+    // the partner's word is a round trip to HBM for cross-CU teams
+    if (seen_prog >= need) return;
     // bounded spin: a protocol bug must surface as an error, never as a hung GPU
-    for (int spin = 0; prog_get(src) < need; ++spin) {
+    for (int spin = 0; (seen_prog = prog_get(src)) < need; ++spin) {
       if (spin > (1 << 20)) {  // ~0.5 s; then fail fast: no further waits, host reports the error
         if (L == 0) atomicExch(A.errflag, 1);
         team_failed = true;
