@@ -12,6 +12,7 @@ LIB_PATH = os.environ.get("BIALIGN_LIB_OVERRIDE") or os.path.join(HERE, "libbial
 
 ABI_VERSION = 7
 RUN_FILL_ONLY = 1
+RUN_ASYNC = 2
 REC_AUTO, REC_AFFINE, REC_LINEAR = 0, 1, 2
 MAX_SHIFT = 5
 
@@ -72,6 +73,7 @@ SYMBOLS = [
     ("bialign_batch_destroy", None, [ctypes.c_void_p]),
     ("bialign_batch_get_info", ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(BatchInfo)]),
     ("bialign_batch_run", ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint32]),
+    ("bialign_batch_wait", ctypes.c_int, [ctypes.c_void_p]),
     ("bialign_batch_get_timing", ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(Timing)]),
     ("bialign_batch_get_scores", ctypes.c_int, [ctypes.c_void_p, c_i32p]),
     ("bialign_batch_get_traces", ctypes.c_int, [ctypes.c_void_p, c_u8p, c_i64p, c_i32p, c_i32p]),

@@ -262,6 +262,7 @@ int bialign_engine_create(int device, bialign_engine** out) {
   e->device = device;
   e->num_cu = prop.multiProcessorCount;
   hipError_t err = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
+  if (err == hipSuccess) err = hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking);
   for (int i = 0; i < 4 && err == hipSuccess; ++i) err = hipEventCreate(&e->ev[i]);
   if (err != hipSuccess) {
     bialign_engine_destroy(e);
@@ -277,6 +278,7 @@ void bialign_engine_destroy(bialign_engine* e) {
   for (auto& ev : e->ev)
     if (ev) (void)hipEventDestroy(ev);
   if (e->stream) (void)hipStreamDestroy(e->stream);
+  if (e->copy_stream) (void)hipStreamDestroy(e->copy_stream);
   delete e;
 }
 
@@ -365,7 +367,7 @@ int bialign_batch_create(bialign_engine* eng, const bialign_params* prm, const b
   // ---- chunking under the HBM budget; inside a chunk longest sweeps first
   size_t free_b = 0, total_b = 0;
   HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-  free_b += eng->layer_cache.n * sizeof(int32_t);  // reused or released below, ours either way
+  free_b += (eng->layer_cache.n + eng->layer_cache2.n) * sizeof(int32_t);  // reused or released below, ours either way
   int64_t budget = hbm_budget > 0 ? hbm_budget : (int64_t)(free_b * 0.85);
   budget = std::min<int64_t>(budget, (int64_t)(free_b * 0.95));
   const int64_t budget_dw = budget / 4;
@@ -426,8 +428,8 @@ int bialign_batch_create(bialign_engine* eng, const bialign_params* prm, const b
     std::stable_sort(b->order.begin() + b->chunk_begin[c], b->order.begin() + b->chunk_begin[c + 1],
                      [&](int x, int y) { return b->pairs[x].G > b->pairs[y].G; });
 
-  // ---- upload
-  hipStream_t st = eng->stream;
+  // ---- upload (own stream: a batch can be prepared while another one sweeps)
+  hipStream_t st = eng->copy_stream;
   HIP_TRY(b->d_pairs.upload(b->pairs.data(), b->pairs.size(), st));
   HIP_TRY(b->d_order.upload(b->order.data(), b->order.size(), st));
   HIP_TRY(b->d_s1.upload(sc->s1, (size_t)sc->k1 * sc->k1, st));
@@ -440,10 +442,14 @@ int bialign_batch_create(bialign_engine* eng, const bialign_params* prm, const b
   HIP_TRY(b->d_cls_b.upload(b->dense ? zeros.data() : pr->cls_b, tot_b, st));
   if (b->dense) HIP_TRY(b->d_mu2.upload(pr->mu2_dense, (size_t)tot_mu2, st));
   const size_t layer_dw = (size_t)b->max_chunk_dwords + 16;  // slack: ghost tail pieces are read 16 B wide
-  if (eng->layer_cache.p && eng->layer_cache.n >= layer_dw) {
-    b->d_layers.swap(eng->layer_cache);
+  DevBuf<int32_t>* slot = nullptr;  // the smallest cached buffer that is large enough
+  for (DevBuf<int32_t>* c : {&eng->layer_cache, &eng->layer_cache2})
+    if (c->p && c->n >= layer_dw && (!slot || c->n < slot->n)) slot = c;
+  if (slot) {
+    b->d_layers.swap(*slot);
   } else {
     eng->layer_cache.release();
+    eng->layer_cache2.release();
     HIP_TRY(b->d_layers.alloc(layer_dw));
   }
   if (getenv("BIALIGN_DEBUG")) {  // placement study: address and plain streaming-write rate of the layer buffer
@@ -467,7 +473,9 @@ int bialign_batch_create(bialign_engine* eng, const bialign_params* prm, const b
   HIP_TRY(b->d_trace.alloc(b->trace_bytes));
   HIP_TRY(hipMemsetAsync(b->d_tlen.p, 0, sizeof(int32_t) * pr->npairs, st));
   HIP_TRY(hipMemsetAsync(b->d_complete.p, 0, sizeof(int32_t) * pr->npairs, st));
-  HIP_TRY(hipStreamSynchronize(st));
+  HIP_TRY(hipEventCreateWithFlags(&b->uploaded, hipEventDisableTiming));
+  HIP_TRY(hipEventRecord(b->uploaded, st));
+  HIP_TRY(hipStreamSynchronize(st));  // the caller's host arrays may go away now
   *out = b.release();
   return BIALIGN_OK;
 }
@@ -476,9 +484,12 @@ void bialign_batch_destroy(bialign_batch* b) {
   if (!b) return;
   (void)hipSetDevice(b->eng->device);
   bialign_engine* eng = b->eng;
-  if (b->d_layers.p && b->d_layers.n > eng->layer_cache.n) {
+  if (b->pending) (void)hipEventSynchronize(b->evs.back());  // its kernels still use the buffers freed below
+  if (b->d_layers.p) {  // keep the buffer for the next batch: a free slot, else in place of a smaller one
     (void)hipStreamSynchronize(eng->stream);
-    eng->layer_cache.swap(b->d_layers);  // keep the larger buffer for the next batch
+    DevBuf<int32_t>* slot = !eng->layer_cache.p ? &eng->layer_cache : (!eng->layer_cache2.p ? &eng->layer_cache2 : nullptr);
+    if (!slot) slot = eng->layer_cache.n <= eng->layer_cache2.n ? &eng->layer_cache : &eng->layer_cache2;
+    if (!slot->p || b->d_layers.n > slot->n) slot->swap(b->d_layers);
   }
   delete b;
 }
@@ -534,6 +545,7 @@ int bialign_engine_trim(bialign_engine* e) {
   if (!e) return fail(BIALIGN_E_INVALID, "NULL argument");
   HIP_TRY(hipSetDevice(e->device));
   e->layer_cache.release();
+  e->layer_cache2.release();
   return BIALIGN_OK;
 }
 
@@ -552,21 +564,50 @@ int bialign_batch_get_info(const bialign_batch* b, bialign_batch_info* info) {
   return BIALIGN_OK;
 }
 
+int bialign_batch_wait(bialign_batch* b) {
+  if (!b) return fail(BIALIGN_E_INVALID, "NULL batch");
+  if (!b->pending) return BIALIGN_OK;
+  HIP_TRY(hipSetDevice(b->eng->device));
+  b->pending = false;
+  HIP_TRY(hipEventSynchronize(b->evs.back()));
+  const int nchunks = (int)b->chunk_begin.size() - 1;
+  for (int c = 0; c < nchunks; ++c) {
+    float f = 0, t = 0;
+    HIP_TRY(hipEventElapsedTime(&f, b->evs[3 * c], b->evs[3 * c + 1]));
+    HIP_TRY(hipEventElapsedTime(&t, b->evs[3 * c + 1], b->evs[3 * c + 2]));
+    b->timing.fill_ms += f;
+    b->timing.traceback_ms += t;
+  }
+  int rc_err = check_device_error(b);
+  if (rc_err) return rc_err;
+  b->ran = true;
+  b->ran_trace = b->pending_trace;
+  return BIALIGN_OK;
+}
+
 int bialign_batch_run(bialign_batch* b, uint32_t flags) {
   if (!b) return fail(BIALIGN_E_INVALID, "NULL batch");
+  int rc = bialign_batch_wait(b);  // one run of a batch at a time
+  if (rc) return rc;
   HIP_TRY(hipSetDevice(b->eng->device));
   const bool do_trace = !(flags & BIALIGN_RUN_FILL_ONLY) && (!b->lean || b->lean_trace);
   const DeviceBatch v = b->view();
   hipStream_t st = b->eng->stream;
-  hipEvent_t* ev = b->eng->ev;
   b->timing = bialign_timing{};
+  b->ran = b->ran_trace = false;
   const int nchunks = (int)b->chunk_begin.size() - 1;
-  for (int c = 0; c < nchunks; ++c) {
+  while ((int)b->evs.size() < 3 * nchunks) {
+    hipEvent_t e = nullptr;
+    HIP_TRY(hipEventCreate(&e));
+    b->evs.push_back(e);
+  }
+  HIP_TRY(hipStreamWaitEvent(st, b->uploaded, 0));
+  for (int c = 0; c < nchunks; ++c) {  // stream order keeps chunk c's traceback ahead of chunk c+1's sweep
     const int first = b->chunk_begin[c], count = b->chunk_begin[c + 1] - first;
-    HIP_TRY(hipEventRecord(ev[0], st));
-    int rc = launch_fill(b, v, first, count);
+    HIP_TRY(hipEventRecord(b->evs[3 * c], st));
+    rc = launch_fill(b, v, first, count);
     if (rc) return rc;
-    HIP_TRY(hipEventRecord(ev[1], st));
+    HIP_TRY(hipEventRecord(b->evs[3 * c + 1], st));
     if (!b->lean) {  // (with LEAN records the sweep itself wrote the scores)
       rc = launch_traceback(b, v, first, count, do_trace);
       if (rc) return rc;
@@ -574,34 +615,27 @@ int bialign_batch_run(bialign_batch* b, uint32_t flags) {
       rc = lean_traceback_rounds(b, v, first, count);
       if (rc) return rc;
     }
-    HIP_TRY(hipEventRecord(ev[2], st));
-    HIP_TRY(hipEventSynchronize(ev[2]));
-    float f = 0, t = 0;
-    HIP_TRY(hipEventElapsedTime(&f, ev[0], ev[1]));
-    HIP_TRY(hipEventElapsedTime(&t, ev[1], ev[2]));
-    b->timing.fill_ms += f;
-    b->timing.traceback_ms += t;
+    HIP_TRY(hipEventRecord(b->evs[3 * c + 2], st));
     b->timing.fill_launches += 1;
     b->timing.traceback_launches += 1;
     b->timing.waves_per_pair = std::abs(b->last_team);
     b->timing.cross_cu = b->last_team < 0;
   }
-  HIP_TRY(hipStreamSynchronize(st));
-  int rc_err = check_device_error(b);
-  if (rc_err) return rc_err;
-  b->ran = true;
-  b->ran_trace = do_trace;
-  return BIALIGN_OK;
+  b->pending = true;
+  b->pending_trace = do_trace;
+  return (flags & BIALIGN_RUN_ASYNC) ? BIALIGN_OK : bialign_batch_wait(b);
 }
 
 int bialign_batch_get_timing(const bialign_batch* b, bialign_timing* t) {
   if (!b || !t) return fail(BIALIGN_E_INVALID, "NULL argument");
+  if (int rc = bialign_batch_wait(const_cast<bialign_batch*>(b))) return rc;
   *t = b->timing;
   return BIALIGN_OK;
 }
 
 int bialign_batch_get_scores(const bialign_batch* b, int32_t* scores) {
   if (!b || !scores) return fail(BIALIGN_E_INVALID, "NULL argument");
+  if (int rc = bialign_batch_wait(const_cast<bialign_batch*>(b))) return rc;
   if (!b->ran) return fail(BIALIGN_E_INVALID, "bialign_batch_run has not been called");
   HIP_TRY(hipSetDevice(b->eng->device));
   HIP_TRY(hipMemcpy(scores, b->d_scores.p, sizeof(int32_t) * b->npairs, hipMemcpyDeviceToHost));
@@ -611,6 +645,7 @@ int bialign_batch_get_scores(const bialign_batch* b, int32_t* scores) {
 int bialign_batch_get_traces(const bialign_batch* b, uint8_t* trace, int64_t* trace_off, int32_t* trace_len,
                              int32_t* complete) {
   if (!b || !trace || !trace_off || !trace_len || !complete) return fail(BIALIGN_E_INVALID, "NULL argument");
+  if (int rc = bialign_batch_wait(const_cast<bialign_batch*>(b))) return rc;
   if (b->lean && !b->lean_trace)
     return fail(BIALIGN_E_INVALID, "batch was created with BIALIGN_BATCH_SCORE_ONLY: it holds no layers to trace back");
   if (!b->ran || !b->ran_trace) return fail(BIALIGN_E_INVALID, "no traceback has been run on this batch");
@@ -625,6 +660,7 @@ int bialign_batch_get_traces(const bialign_batch* b, uint8_t* trace, int64_t* tr
 int bialign_batch_dump_layers(bialign_batch* b, int32_t pair, int32_t* out) {
   if (!b || !out) return fail(BIALIGN_E_INVALID, "NULL argument");
   if (pair < 0 || pair >= b->npairs) return fail(BIALIGN_E_INVALID, "pair %d out of range", pair);
+  if (int rc = bialign_batch_wait(b)) return rc;
   if (b->lean) return fail(BIALIGN_E_INVALID, "batch was created with reduced layer storage (SCORE_ONLY / LEAN_TRACE): it holds no full layers");
   HIP_TRY(hipSetDevice(b->eng->device));
   hipStream_t st = b->eng->stream;

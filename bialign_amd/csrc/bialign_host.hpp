@@ -77,11 +77,13 @@ struct bialign_engine {
   int device = 0;
   int num_cu = 256;
   hipStream_t stream = nullptr;
+  hipStream_t copy_stream = nullptr;  // uploads of new batches: not ordered behind running sweeps
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   // Layer buffer kept between batches: hipMalloc / hipFree of tens of GB cost 0.1-6 s, the
   // sweep itself ~20 ms.  A batch takes it at creation when it is large enough and hands
   // the larger of (its own, the cached one) back at destruction; bialign_engine_trim frees it.
   DevBuf<int32_t> layer_cache;
+  DevBuf<int32_t> layer_cache2;  // second slot: filled only when two batches were alive at once (pipelined use)
 };
 
 struct bialign_batch {
@@ -109,6 +111,14 @@ struct bialign_batch {
   int k1 = 0, k2 = 0;
   bialign_timing timing{};
   bool ran = false, ran_trace = false;
+  bool pending = false, pending_trace = false;  // an enqueued run not yet waited for
+  std::vector<hipEvent_t> evs;                  // three per chunk: before fill, after fill, after traceback
+  hipEvent_t uploaded = nullptr;                // inputs are in HBM (recorded on the copy stream)
+  ~bialign_batch() {
+    for (hipEvent_t e : evs)
+      if (e) (void)hipEventDestroy(e);
+    if (uploaded) (void)hipEventDestroy(uploaded);
+  }
 
   DeviceBatch view() const {
     DeviceBatch v{};

@@ -144,8 +144,13 @@ class Batch:
     def __del__(self):
         self.close()
 
-    def run(self, fill_only=False):
-        check(lib.bialign_batch_run(self._h, _lib.RUN_FILL_ONLY if fill_only else 0))
+    def run(self, fill_only=False, wait=True):
+        """Fill (+ traceback).  ``wait=False`` only enqueues the kernels (BIALIGN_RUN_ASYNC): the host
+        may encode / create the next batch meanwhile; ``wait()`` or any result getter completes the run."""
+        check(lib.bialign_batch_run(self._h, (_lib.RUN_FILL_ONLY if fill_only else 0) | (0 if wait else _lib.RUN_ASYNC)))
+
+    def wait(self):
+        check(lib.bialign_batch_wait(self._h))
 
     def timing(self):
         t = _lib.Timing()

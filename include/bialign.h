@@ -50,6 +50,7 @@ extern "C" {
 
 /* run flags */
 #define BIALIGN_RUN_FILL_ONLY 1u /* optimize() without traceback() */
+#define BIALIGN_RUN_ASYNC 2u     /* enqueue and return; bialign_batch_wait (or any result getter) completes the run */
 
 /* bialign_params.flags.  SCORE_ONLY: the batch will only ever be asked for scores (optimize()
  * without a later traceback(), e.g. all-against-all scoring): the sweep keeps just the rows the
@@ -165,6 +166,10 @@ int bialign_batch_get_info(const bialign_batch* b, bialign_batch_info* info);
  * by BiAligner.traceback() (pyx:513-586), for every pair, chunk by chunk.
  * Returns after the device work has completed. */
 int bialign_batch_run(bialign_batch* b, uint32_t flags);
+/* Completes a BIALIGN_RUN_ASYNC run: waits for the batch's kernels, collects kernel times and the
+ * device error flag.  A no-op when nothing is pending.  Lets the host prepare the next batch
+ * (encoding, bialign_batch_create: uploads go through their own stream) while this one sweeps. */
+int bialign_batch_wait(bialign_batch* b);
 int bialign_batch_get_timing(const bialign_batch* b, bialign_timing* t);
 
 /* Optimal scores: the return value of optimize() (pyx:471, 509). */

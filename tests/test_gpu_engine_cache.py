@@ -67,3 +67,29 @@ def test_reserve_picks_a_buffer_and_batches_use_it():
     b.close(); b2.close()
     assert eng.reserve(16 << 20, tries=1) > 0   # smaller request: the cached buffer is the candidate
     eng.close()
+
+
+def test_async_run_two_batches_in_flight():
+    """run(wait=False) only enqueues; getters complete the run; a second batch can be created and
+    enqueued meanwhile (its uploads use their own stream); both buffers return to the engine."""
+    from bialign_amd.batch import make_batch
+    from bialign_amd.engine import Engine
+    eng = Engine(0)
+    params = dict(synth.PROTEIN_PARAMS)
+    pa = [synth.protein_pair(2000 + t, 200, 190) for t in range(8)]
+    pb = [synth.protein_pair(2100 + t, 150, 210) for t in range(8)]
+    ref_a = solve(eng, pa, params); ref_a[0].close()
+    ref_b = solve(eng, pb, params); ref_b[0].close()
+    a = make_batch(pa, params, engine=eng); a.run(wait=False)
+    b = make_batch(pb, params, engine=eng); b.run(wait=False)      # enqueued behind a
+    a.wait(); a.wait()                                               # idempotent
+    got_b = [int(v) for v in b.scores()], [t.tolist() for t in b.traces()[0]]   # implicit wait
+    got_a = [int(v) for v in a.scores()], [t.tolist() for t in a.traces()[0]]
+    assert got_a == ref_a[1] and got_b == ref_b[1]
+    assert a.timing()["fill_ms"] > 0 and b.timing()["fill_launches"] == 1
+    a.run(wait=False); a.run()                                       # a new run first completes the pending one
+    assert [int(v) for v in a.scores()] == ref_a[1][0]
+    a.close(); b.close()
+    c, got_c = solve(eng, pa, params)                                # takes one of the two cached buffers
+    assert got_c == ref_a[1]
+    c.close(); eng.close()
