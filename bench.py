@@ -58,6 +58,10 @@ def main():
     ap.add_argument("--len", type=int, default=512, dest="length")
     ap.add_argument("--max_shift", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="2 = two engines (HIP streams) with one resident batch each, steps enqueued alternately: the next "
+                         "step's sweep fills the SIMDs the current one's stragglers leave idle.  Per-launch kernel times "
+                         "(and the roofline object computed from them) are then those of overlapping launches.")
     ap.add_argument("--reserve-tries", type=int, default=4,
                     help="candidate placements of the layer buffer probed in setup (Engine.reserve); 1 = take the first")
     args = ap.parse_args()
@@ -102,6 +106,14 @@ def main():
         info = batch.info
     batch.run()  # engine warm-up, not a step: first launch loads the code objects and ramps the clocks
 
+    lanes = [batch]  # --streams 2: a second engine + batch over the same pairs, steps alternate between them
+    if args.streams == 2:
+        engine2 = Engine(device)
+        if args.reserve_tries > 1 and not rehearse:
+            engine2.reserve(info["hbm_layer_bytes"] + 64, tries=args.reserve_tries)
+        lanes.append(make_batch(pairs, params, engine=engine2))
+        lanes[1].run()
+
     def barrier():
         if world > 1:
             dist.barrier()
@@ -115,20 +127,42 @@ def main():
         # the one collective: all_gather of the scores over RCCL/xGMI (no-op at N=1)
         return gather_scores(scores, args.pairs * world)
 
-    for _ in range(args.warmup):
-        step()
+    def steps_pipelined(count):
+        """count steps over two lanes: step k+1 is enqueued before step k's results are taken."""
+        acc = [0.0, 0.0, 0]
+        if count:
+            lanes[0].run(wait=False)
+        for k in range(count):
+            if k + 1 < count:
+                lanes[(k + 1) % 2].run(wait=False)
+            cur = lanes[k % 2]
+            gather_scores(cur.scores(), args.pairs * world)   # waits for step k
+            t = cur.timing()
+            acc[0] += t["fill_ms"]; acc[1] += t["traceback_ms"]; acc[2] += t["fill_launches"]
+        return acc
+
     fill_ms = tb_ms = 0.0
     launches = 0
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-        t = batch.timing()               # HIP-event times on the engine's stream
-        fill_ms += t["fill_ms"]
-        tb_ms += t["traceback_ms"]
-        launches += t["fill_launches"]
-    barrier()
-    elapsed = time.perf_counter() - t0
+    if len(lanes) == 2:
+        steps_pipelined(args.warmup)
+        barrier()
+        t0 = time.perf_counter()
+        fill_ms, tb_ms, launches = steps_pipelined(args.steps)
+        barrier()
+        elapsed = time.perf_counter() - t0
+    else:
+        for _ in range(args.warmup):
+            step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+            t = batch.timing()               # HIP-event times on the engine's stream
+            fill_ms += t["fill_ms"]
+            tb_ms += t["traceback_ms"]
+            launches += t["fill_launches"]
+        barrier()
+        elapsed = time.perf_counter() - t0
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -164,7 +198,7 @@ def main():
                        "pairs_per_gpu": args.pairs, "len": args.length, "max_shift": args.max_shift,
                        "cells_per_gpu": info["cells"], "chunks_per_step": info["nchunks"],
                        "sharding": f"pairs sharded over {world} rank(s), no data-path collective",
-                       "layer_buffer_placement": placement},
+                       "layer_buffer_placement": placement, "streams": args.streams},
             "kernel_ms": {"fill": fill_ms / args.steps, "traceback": tb_ms / args.steps},
             "roofline": {"bound": "hbm", "kernel": "fill_affine_kernel", "achieved": achieved,
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
@@ -176,7 +210,8 @@ def main():
         elif not args.no_cpu_baseline:
             line["cpu_baseline"] = None  # measured at N=1 only
         print(json.dumps(line), flush=True)
-    batch.close()
+    for lane in lanes:
+        lane.close()
     if world > 1:
         dist.destroy_process_group()
 

@@ -22,7 +22,7 @@ for cycle in range(E("AB_CYCLES", 6)):
     t = b.timing()
     print(f"cycle {cycle}: fill ms " + " ".join(f"{x:.2f}" for x in ts) +
           f"   team {t['waves_per_pair']}{'x' if t['cross_cu'] else ''} chunks {b.info['nchunks']}", flush=True)
-    best.append(min(ts[2:]))
+    best.append(min(ts[2:] or ts))
     b.close()
     default_engine().trim()
 print(f"levels: " + " ".join(f"{x:.2f}" for x in sorted(best)))
