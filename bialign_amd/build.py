@@ -12,8 +12,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
-DEPS = [os.path.join(CSRC, f) for f in ("bialign_capi.hip", "bialign_inst.hip", "bialign_host.hpp",
-                                        "bialign_kernels.hpp")]
+DEPS = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".hpp"))]
 DEPS.append(os.path.join(os.path.dirname(HERE), "include", "bialign.h"))
 OUT = os.path.join(HERE, "libbialign_hip.so")
 HOST_SRC = os.path.join(CSRC, "bialign_host.c")
