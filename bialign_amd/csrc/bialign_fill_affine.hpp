@@ -92,7 +92,7 @@ __global__ void __launch_bounds__(64 * TW) fill_affine_kernel(const DeviceBatch 
     kk = blockIdx.x - slot * A.resw_k;
     Qbase = (ts0.started ? ts0.strip : pd.NS - 1) - kk;
     if (Qbase < 0) return;
-    jlim = (ts0.started && kk == 0) ? ts0.j : m;
+    jlim = ts0.started ? ts0.j : m;  // the walk never moves right: no strip of this round is entered beyond its column
   }
   const int L = threadIdx.x & 63;
   const int wl = TW == 1 ? 0 : __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave in workgroup

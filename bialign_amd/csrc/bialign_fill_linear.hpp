@@ -31,7 +31,7 @@ __global__ void __launch_bounds__(64 * TW) fill_linear_kernel(const DeviceBatch 
     kk = blockIdx.x - pslot * A.resw_k;
     Qbase = (ts0.started ? ts0.strip : pd.NS - 1) - kk;
     if (Qbase < 0) return;
-    jlim = (ts0.started && kk == 0) ? ts0.j : m;
+    jlim = ts0.started ? ts0.j : m;  // the walk never moves right: no strip of this round is entered beyond its column
   }
   const int L = threadIdx.x & 63;
   const int w = TW == 1 ? 0 : __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
