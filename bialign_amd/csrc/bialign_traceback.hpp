@@ -47,8 +47,11 @@ __device__ __forceinline__ TraceInputs stage_trace_inputs(const DeviceBatch& A, 
 }
 
 __device__ __forceinline__ int wave_min16(int v) {  // min over lanes 0..15, valid in every lane < 16
-#pragma unroll
-  for (int d = 1; d < 16; d <<= 1) v = min(v, __shfl_xor(v, d, 16));
+  // four DPP row rotations (a row = 16 lanes) instead of four trips through the LDS crossbar
+  v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x128 /* row_ror:8 */, 0xf, 0xf, false));
+  v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x124 /* row_ror:4 */, 0xf, 0xf, false));
+  v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x122 /* row_ror:2 */, 0xf, 0xf, false));
+  v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x121 /* row_ror:1 */, 0xf, 0xf, false));
   return v;
 }
 
