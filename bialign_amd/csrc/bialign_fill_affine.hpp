@@ -466,7 +466,7 @@ __global__ void __launch_bounds__(64 * TW) fill_affine_kernel(const DeviceBatch 
             store_chunk<XCU>(dst + c * R_::CH + slot * 4, v);
           }
         }
-        if (bb == W - 1) {
+        if (LEAN && bb == W - 1) {
 #pragma unroll
           for (int t = 0; t < TAIL; ++t) {
             if (XCU)
@@ -474,6 +474,22 @@ __global__ void __launch_bounds__(64 * TW) fill_affine_kernel(const DeviceBatch 
                                  __HIP_MEMORY_SCOPE_AGENT);
             else
               dst[NCH4 * R_::CH + slot * TAIL + t] = outv[4 * NCH4 + t];
+          }
+        }
+      }
+      if (!LEAN && bb == W - 1) {
+        // the tail is stored by ALL 64 lanes (Rec::TAILSLOTS): the spare ones fill the record up to its end
+        const bool wave_stores = BIALIGN_EXP != 1 && (INTERIOR || __builtin_amdgcn_ballot_w64(tile_act && !ghost) != 0) &&
+                                 ((!XCU && TW == 1) || rec <= rec_last);
+        if (wave_stores) {
+          const int tslot = (live && !ghost) ? slot : R_::SL + (L < W ? L : W + (L - R * W));
+#pragma unroll
+          for (int t = 0; t < TAIL; ++t) {
+            if (XCU)
+              __hip_atomic_store(dst + NCH4 * R_::CH + tslot * TAIL + t, outv[4 * NCH4 + t], __ATOMIC_RELAXED,
+                                 __HIP_MEMORY_SCOPE_AGENT);
+            else
+              dst[NCH4 * R_::CH + tslot * TAIL + t] = outv[4 * NCH4 + t];
           }
         }
       }

@@ -229,8 +229,17 @@ __global__ void __launch_bounds__(64 * TW) fill_linear_kernel(const DeviceBatch 
         v.x = outv[4 * c]; v.y = outv[4 * c + 1]; v.z = outv[4 * c + 2]; v.w = outv[4 * c + 3];
         *reinterpret_cast<v4i*>(dst + c * R_::CH + slot * 4) = v;
       }
+      if (LEAN) {
 #pragma unroll
-      for (int t = 0; t < TAIL; ++t) dst[NCH4 * R_::CH + slot * TAIL + t] = outv[4 * NCH4 + t];
+        for (int t = 0; t < TAIL; ++t) dst[NCH4 * R_::CH + slot * TAIL + t] = outv[4 * NCH4 + t];
+      }
+    }
+    if (!LEAN && __builtin_amdgcn_ballot_w64(tile_act && !ghost) != 0 && (T == 1 || rec <= rec_last)) {
+      // tail by all 64 lanes (Rec::TAILSLOTS), as in the affine kernel
+      const int tslot = (live && !ghost) ? L - W : R_::SL + (L < W ? L : W + (L - R * W));
+      int32_t* dst = sto + (int64_t)rec * RECDW;
+#pragma unroll
+      for (int t = 0; t < TAIL; ++t) dst[NCH4 * R_::CH + tslot * TAIL + t] = outv[4 * NCH4 + t];
     }
     ++jj;
     if (!RESW && jj == P) {

@@ -63,7 +63,7 @@ struct Geo {
 
 // Record geometry: one record per step, ND dwords for each of the SL = RR*W real lanes
 // (ghost and idle lanes own no storage), as NCH4 chunks [chunk][slot][4 dwords] followed by a
-// [slot][TAIL] tail, everything packed: a wave-wide store instruction writes one contiguous
+// [slot][TAIL] tail (64 slots, see TAILSLOTS), everything packed: a wave-wide store instruction writes one contiguous
 // run of SL*16 bytes and consecutive instructions / steps continue where the last one ended,
 // so every byte of a pair's region is written and L2 assembles full lines.
 //   LEAN records (score-only batches): nobody will trace back, so a step keeps only what the
@@ -76,7 +76,11 @@ struct Rec {
   static constexpr int NCH4 = ND / 4;
   static constexpr int TAIL = ND % 4;
   static constexpr int CH = SL * 4;            // dwords per chunk
-  static constexpr int RECDW = LEAN ? (SL * ND + 3) / 4 * 4 : SL * ND;  // 16-byte pieces stay aligned
+  // The tail has 64 slots, not SL: the spare lanes (ghost row, idle lanes) store don't-care values into the
+  // last ones, so that a record ends on a 64-lane boundary -- at s=1 (6 x 960 + 768 B) it is 51 whole
+  // 128-byte lines and consecutive records of a wave never share a line (3 % of the fill time).
+  static constexpr int TAILSLOTS = LEAN ? SL : 64;
+  static constexpr int RECDW = LEAN ? (SL * ND + 3) / 4 * 4 : NCH4 * CH + TAILSLOTS * TAIL;  // 16-byte pieces stay aligned
   __host__ __device__ static inline int64_t dword(int64_t g, int slot, int d) {
     return d < 4 * NCH4 ? g * RECDW + (d >> 2) * CH + slot * 4 + (d & 3)
                         : g * RECDW + NCH4 * CH + slot * TAIL + (d - 4 * NCH4);
