@@ -341,10 +341,12 @@ __global__ void __launch_bounds__(64 * TW) fill_affine_kernel(const DeviceBatch 
     // the store.  Each chunk is issued as soon as its four values exist, spreading the
     // stores over the step.
     const int rec = g + rec_base;  // lanes of two strips (straddling steps) hit two records
-    const bool do_store = BIALIGN_EXP != 1 && live && (LEAN ? il == R - 1 : !ghost) &&
+    const int pad_idx = L < W ? L : (L >= R * W ? W + (L - R * W) : 64);  // spare lanes: ghost row, idle lanes
+    const bool pad_lane = !LEAN && pad_idx < R_::SLP - R_::SL;             // ... that own a pad slot of every chunk
+    const bool do_store = BIALIGN_EXP != 1 && ((live && (LEAN ? il == R - 1 : !ghost)) || pad_lane) &&
                           (INTERIOR || __builtin_amdgcn_ballot_w64(tile_act && !ghost) != 0) &&
                           ((!XCU && TW == 1) || rec <= rec_last);
-    const int slot = LEAN ? aa : L - W;  // storage slot of a real lane
+    const int slot = LEAN ? aa : (pad_lane ? R_::SL + pad_idx : L - W);  // storage slot of this lane
     if (__builtin_amdgcn_ballot_w64(do_store) != 0) vm_younger += GF::STORES_PER_STEP;
     int32_t* const dst = BIALIGN_EXP == 2
                              ? A.layers + ((int64_t)(blockIdx.x & 255) << 18) + (int64_t)(g & 31) * RECDW
@@ -482,7 +484,7 @@ __global__ void __launch_bounds__(64 * TW) fill_affine_kernel(const DeviceBatch 
         const bool wave_stores = BIALIGN_EXP != 1 && (INTERIOR || __builtin_amdgcn_ballot_w64(tile_act && !ghost) != 0) &&
                                  ((!XCU && TW == 1) || rec <= rec_last);
         if (wave_stores) {
-          const int tslot = (live && !ghost) ? slot : R_::SL + (L < W ? L : W + (L - R * W));
+          const int tslot = (live && !ghost) ? L - W : R_::SL + (L < W ? L : W + (L - R * W));
 #pragma unroll
           for (int t = 0; t < TAIL; ++t) {
             if (XCU)

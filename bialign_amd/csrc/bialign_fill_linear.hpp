@@ -217,11 +217,14 @@ __global__ void __launch_bounds__(64 * TW) fill_linear_kernel(const DeviceBatch 
 
     const int rec = g + rec_base;
     if (LEAN && live && !ghost && aa == S && i == n && jj == m) A.scores[pid] = outv[S];  // pyx:471
-    const bool do_store = __builtin_amdgcn_ballot_w64(tile_act && !ghost) != 0 && live &&
-                          (LEAN ? il == R - 1 : !ghost) && (T == 1 || rec <= rec_last);  // see the affine kernel
+    const int pad_idx = L < W ? L : (L >= R * W ? W + (L - R * W) : 64);
+    const bool pad_lane = !LEAN && pad_idx < R_::SLP - R_::SL;  // spare lanes owning a pad slot (Rec::SLP)
+    const bool do_store = __builtin_amdgcn_ballot_w64(tile_act && !ghost) != 0 &&
+                          ((live && (LEAN ? il == R - 1 : !ghost)) || pad_lane) &&
+                          (T == 1 || rec <= rec_last);  // see the affine kernel
     if (__builtin_amdgcn_ballot_w64(do_store) != 0) vm_younger += GF::STORES_PER_STEP;
     if (do_store) {
-      const int slot = LEAN ? aa : L - W;
+      const int slot = LEAN ? aa : (pad_lane ? R_::SL + pad_idx : L - W);
       int32_t* dst = sto + (int64_t)rec * RECDW;
 #pragma unroll
       for (int c = 0; c < NCH4; ++c) {
