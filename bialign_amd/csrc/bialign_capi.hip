@@ -376,7 +376,7 @@ int bialign_batch_create(bialign_engine* eng, const bialign_params* prm, const b
     for (int p = 0; p < pr->npairs; ++p) {
       PairDesc& d = b->pairs[p];
       int slp = (64 / W - 1) * W;  // Rec<S,NL>::SLP
-      if ((slp + 7) / 8 * 8 - slp <= 2) slp = (slp + 7) / 8 * 8;
+      if ((slp + 7) / 8 * 8 - slp <= BIALIGN_PADMAX) slp = (slp + 7) / 8 * 8;
       const int64_t full_rec = (int64_t)((b->NL * W) / 4) * slp * 4 + 64 * ((b->NL * W) % 4);  // Rec<S,NL>::RECDW per step
       const int64_t lean_dw = (int64_t)d.G * ((W * b->NL * W + 3) / 4 * 4);       // Rec<S,NL,true>::RECDW per step
       const int64_t scratch_dw = (int64_t)(d.m + 2 * (64 / W - 1) + W) * full_rec;  // one strip: m + MAXOFF + 1 records

@@ -42,6 +42,9 @@
 // interior step variant, 4 = always take it
 #define BIALIGN_EXP 0
 #endif
+#ifndef BIALIGN_PADMAX
+#define BIALIGN_PADMAX 2
+#endif
 #ifndef BIALIGN_OPT  // A/B switches of equivalent step code: 1 = fused DPP-min exchange, 2 = ghost rows by branch
 #define BIALIGN_OPT 3
 #endif

@@ -77,7 +77,7 @@ struct Rec {
   static constexpr int TAIL = ND % 4;
   // A chunk holds SLP >= SL slots: where rounding SL up to a multiple of 8 costs at most two slots (s=2: 55 -> 56,
   // s=4: 54 -> 56) the spare lanes write them too and every chunk store covers whole 128-byte lines (-1..2 %).
-  static constexpr int SLP = (!LEAN && (SL + 7) / 8 * 8 - SL <= 2) ? (SL + 7) / 8 * 8 : SL;
+  static constexpr int SLP = (!LEAN && (SL + 7) / 8 * 8 - SL <= BIALIGN_PADMAX) ? (SL + 7) / 8 * 8 : SL;
   static constexpr int CH = SLP * 4;           // dwords per chunk
   // The tail has 64 slots, not SL: the spare lanes (ghost row, idle lanes) store don't-care values into the
   // last ones, so that a record ends on a 64-lane boundary -- at s=1 (6 x 960 + 768 B) it is 51 whole
