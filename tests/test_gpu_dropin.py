@@ -288,3 +288,19 @@ def test_cli_config3_from_files_readme_command(capsys):
               "--structure_weight", "800", "--simmatrix", "BLOSUM62", "--gap_opening_cost", "-150",
               "--gap_cost", "-50", "--max_shift", "1"])
     assert capsys.readouterr().out == want
+
+
+def test_c_abi_from_plain_c(tmp_path):
+    """examples/align_one.c: the boundary used from C alone (gcc, no Python in the process)."""
+    import os
+    import subprocess
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "align_one")
+    subprocess.run(["gcc", "-std=c11", "-I" + os.path.join(repo, "include"), os.path.join(repo, "examples", "align_one.c"),
+                    "-o", exe, "-L" + os.path.join(repo, "bialign_amd"), "-lbialign_hip",
+                    "-Wl,-rpath," + os.path.join(repo, "bialign_amd")], check=True)
+    out = subprocess.run([exe], check=True, capture_output=True, text=True, timeout=300).stdout
+    assert "SCORE: 6800" in out
+    rec = [r for r in load_golden("known_answers.json") if r["name"] == "readme_rna_toy"][0]
+    want = "".join("%x" % (c[0] * 8 + c[1] * 4 + c[2] * 2 + c[3]) for c in rec["trace"])
+    assert f"TRACE ({len(rec['trace'])} columns, complete): {want}" in out
