@@ -274,6 +274,10 @@ int bialign_engine_create(int device, bialign_engine** out) {
 
 void bialign_engine_destroy(bialign_engine* e) {
   if (!e) return;
+  if (e->live_batches > 0) {  // destroy order is the caller's business (garbage collectors pick any): the
+    e->closing = true;        // engine goes when its last batch goes
+    return;
+  }
   (void)hipSetDevice(e->device);
   for (auto& ev : e->ev)
     if (ev) (void)hipEventDestroy(ev);
@@ -478,6 +482,7 @@ int bialign_batch_create(bialign_engine* eng, const bialign_params* prm, const b
   HIP_TRY(hipEventCreateWithFlags(&b->uploaded, hipEventDisableTiming));
   HIP_TRY(hipEventRecord(b->uploaded, st));
   HIP_TRY(hipStreamSynchronize(st));  // the caller's host arrays may go away now
+  ++eng->live_batches;
   *out = b.release();
   return BIALIGN_OK;
 }
@@ -487,13 +492,14 @@ void bialign_batch_destroy(bialign_batch* b) {
   (void)hipSetDevice(b->eng->device);
   bialign_engine* eng = b->eng;
   if (b->pending) (void)hipEventSynchronize(b->evs.back());  // its kernels still use the buffers freed below
-  if (b->d_layers.p) {  // keep the buffer for the next batch: a free slot, else in place of a smaller one
+  if (b->d_layers.p && !eng->closing) {  // keep the buffer for the next batch: a free slot, else in place of a smaller one
     (void)hipStreamSynchronize(eng->stream);
     DevBuf<int32_t>* slot = !eng->layer_cache.p ? &eng->layer_cache : (!eng->layer_cache2.p ? &eng->layer_cache2 : nullptr);
     if (!slot) slot = eng->layer_cache.n <= eng->layer_cache2.n ? &eng->layer_cache : &eng->layer_cache2;
     if (!slot->p || b->d_layers.n > slot->n) slot->swap(b->d_layers);
   }
   delete b;
+  if (--eng->live_batches == 0 && eng->closing) bialign_engine_destroy(eng);
 }
 
 // streaming-write rate of a buffer in GB/s (second of two memset passes)

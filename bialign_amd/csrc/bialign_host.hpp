@@ -82,6 +82,8 @@ struct bialign_engine {
   // Layer buffer kept between batches: hipMalloc / hipFree of tens of GB cost 0.1-6 s, the
   // sweep itself ~20 ms.  A batch takes it at creation when it is large enough and hands
   // the larger of (its own, the cached one) back at destruction; bialign_engine_trim frees it.
+  int live_batches = 0;   // batches created on this engine and not yet destroyed
+  bool closing = false;   // bialign_engine_destroy was called while batches were alive: the last one finishes the job
   DevBuf<int32_t> layer_cache;
   DevBuf<int32_t> layer_cache2;  // second slot: filled only when two batches were alive at once (pipelined use)
 };

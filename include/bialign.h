@@ -140,6 +140,7 @@ const char* bialign_last_error(void);
  * (kept for the next one: allocating tens of GB costs far more than sweeping them).  An engine
  * and its batches are used from one thread at a time. */
 int bialign_engine_create(int device, bialign_engine** out);
+/* Safe in any order with bialign_batch_destroy: an engine with live batches goes when its last batch goes. */
 void bialign_engine_destroy(bialign_engine* eng);
 /* Give the cached layer buffer back to the device (e.g. before another library needs the HBM). */
 int bialign_engine_trim(bialign_engine* eng);

@@ -1,7 +1,11 @@
 """The engine keeps the layer buffer of a finished batch for the next one (hipMalloc of tens of
 GB costs far more than the sweep).  Results must not depend on whose buffer a batch runs in."""
+import os
+
 import numpy as np
 import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 from bialign_amd import synth
 
@@ -93,3 +97,35 @@ def test_async_run_two_batches_in_flight():
     c, got_c = solve(eng, pa, params)                                # takes one of the two cached buffers
     assert got_c == ref_a[1]
     c.close(); eng.close()
+
+
+def test_destroy_order_is_free():
+    """C ABI: an engine destroyed before its batches lives on until the last batch is gone (garbage
+    collectors finalise cycles in any order); and a script that leaves everything to interpreter exit ends cleanly."""
+    import subprocess
+    import sys
+    from bialign_amd._lib import lib
+    from bialign_amd.batch import make_batch
+    from bialign_amd.engine import Engine
+    eng = Engine(0)
+    b = make_batch([synth.protein_pair(3, 60, 50)], dict(synth.PROTEIN_PARAMS), engine=eng)
+    b.run()
+    want = int(b.scores()[0])
+    h, eng._h = eng._h, None                  # bypass Engine.close(), which would close the batch first
+    lib.bialign_engine_destroy(h)             # deferred: one live batch
+    assert int(b.scores()[0]) == want         # the batch still works
+    b.run()
+    assert int(b.scores()[0]) == want
+    b.close()                                 # ... and takes the engine with it
+    script = "\n".join([
+        "import sys; sys.path.insert(0, %r)" % REPO,
+        "from bialign_amd import synth",
+        "from bialign_amd.batch import make_batch",
+        "from bialign_amd.engine import Engine",
+        "e1, e2 = Engine(0), Engine(0)",
+        "q = [make_batch([synth.protein_pair(k, 40, 40)], dict(synth.PROTEIN_PARAMS), engine=(e1, e2)[k % 2]) for k in range(4)]",
+        "def f():",                      # a function: module globals become a reference cycle
+        "    return [x.run() for x in q]",
+        "f(); print('done')"])
+    out = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "done" in out.stdout, out.stderr[-500:]
