@@ -169,3 +169,19 @@ def test_dense_mu2_form(k, monkeypatch):
     tabs = [rng.integers(-300, 900, size=(n, m)).astype(np.int32) for n, m in shapes]
     for s in (0, 1, 2, 3):
         same(pairs, dict(synth.PROTEIN_PARAMS, max_shift=s), mu2_dense=tabs)
+
+
+def test_async_run_of_lean_and_chunked_batches():
+    """run(wait=False) enqueues all chunks and all re-sweep rounds without touching the host in between."""
+    from bialign_amd.batch import make_batch
+    shapes = [(300, 280), (90, 5), (64, 64), (170, 180), (100, 100), (260, 30)]
+    pairs = [synth.protein_pair(2200 + t, n, m) for t, (n, m) in enumerate(shapes)]
+    params = dict(synth.PROTEIN_PARAMS)
+    full = run(pairs, params)
+    for kw in (dict(lean_trace=True), dict(hbm_budget_bytes=60 << 20), dict(lean_trace=True, hbm_budget_bytes=6 << 20)):
+        b = make_batch(pairs, params, **kw)
+        b.run(wait=False)
+        traces, ok = b.traces()          # implicit wait
+        np.testing.assert_array_equal(b.scores(), full[0])
+        assert [t.tolist() for t in traces] == full[1] and [bool(v) for v in ok] == full[2]
+        b.close()
