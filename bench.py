@@ -107,7 +107,8 @@ def main():
             placement = {"reserve_tries": 1, "probe_gbps": None, "reserve_error": str(e)[:200]}
         batch = make_batch(pairs, params, engine=engine)  # takes the reserved buffer
         info = batch.info
-    batch.run()  # engine warm-up, not a step: first launch loads the code objects and ramps the clocks
+    for _ in range(3):  # engine warm-up, not steps: the first launches load the code objects, touch the buffer's pages
+        batch.run()     # for the first time and ramp the clocks (the first two or three runs of a process are ~10 % slower)
 
     lanes = [batch]  # --streams 2: a second engine + batch over the same pairs, steps alternate between them
     if args.streams == 2:
