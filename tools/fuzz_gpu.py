@@ -21,7 +21,7 @@ while time.time() < t_end:
     params = dict(synth.PROTEIN_PARAMS, max_shift=s, gap_opening_cost=beta, gap_cost=int(rng.integers(-300, 1)),
                   shift_cost=int(rng.integers(-400, 1)), structure_weight=int(rng.integers(0, 1200)))
     npairs = int(rng.integers(1, 9))
-    big = rng.random() < 0.15                   # sometimes multi-strip / team-capable shapes
+    big = rng.random() < float(os.environ.get("FUZZ_BIG", 0.15))   # multi-strip / team-capable shapes
     hi = 420 if big else 90
     shapes = [(int(rng.integers(1, hi)), int(rng.integers(1, hi))) for _ in range(npairs)]
     pairs = [synth.protein_pair(int(rng.integers(1 << 30)), n, m) for n, m in shapes]
