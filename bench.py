@@ -2,16 +2,24 @@
 """Headline benchmark: giga-DP-cells/s of the bi-alignment hot path on MI355X.
 
 One *step* = one pass of the hot path (affine DP fill + traceback, scores
-gathered) over one resident batch of synthetic pairs.  Workload at every N:
-BASELINE.json configs[1] per GPU -- 1024 synthetic protein pairs, len 512,
-BLOSUM62, affine gaps, max_shift=1 (rank r draws pairs seeded 1000 + r*1024 + p;
-weak scaling).  Pairs are independent, so ranks share nothing on the data path;
-the only collective is the final all_gather of int32 scores over RCCL.
+gathered) over one rank's batch of synthetic pairs, inputs resident in HBM.
+
+Workload = what BASELINE.json's metric is quoted on: **1024 synthetic protein
+pairs per GPU, n = m = 1024, BLOSUM62, affine gaps, max_shift = 1** -- config 5's
+per-GPU share (rank r owns pairs [r*1024, (r+1)*1024), pair p
+is drawn from seed 1000 + p).  Its nine int32 layers are 348 GB, so one step is
+two chunks (fill -> traceback -> fill -> traceback) through one 174 GB buffer.
+Pairs are independent: ranks share nothing on the data path, the only collective
+is the final all_gather of int32 scores over RCCL (weak scaling).
 
     python bench.py [--gpus N --steps K --warmup W]
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
-Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement").
+Prints ONE JSON line on rank 0.  At N=1 the line also carries
+`cpu_baseline` (the C oracle on one host core and on all host cores of this box,
+timed BEFORE the GPU is initialised) and `extra.config2` (BASELINE configs[1],
+1024 pairs x len 512, with the default allocation and with a placement-probed
+buffer), both outside the timed region.
 """
 import argparse
 import json
@@ -25,28 +33,75 @@ sys.path.insert(0, REPO)
 HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 
 
-def cpu_baseline(pairs, params, budget_s=18.0, max_pairs=8):
-    """The CPU oracle (oracle/bialign_oracle.c, a literal port of the reference
-    recurrence) timed on ONE host core on the first pairs of the same workload."""
+def _oracle_pair(job):
+    """Worker: the CPU oracle on one synthetic protein pair -> (seconds, cells)."""
+    seed, length, s = job
     from bialign_amd import synth
     from oracle import oracle
-    n_done, cells, spent = 0, 0, 0.0
-    beta, gamma, delta, s = (params["gap_opening_cost"], params["gap_cost"], params["shift_cost"],
-                             params["max_shift"])
-    for sa, sb, ta, tb in pairs[:max_pairs]:
-        n, m = len(sa), len(sb)
-        mu1, mu2 = oracle.mu_tables(sa, sb, ta, tb, params)  # input preparation, not timed
-        t0 = time.perf_counter()
-        _, layers = oracle.affine_fill(n, m, s, beta, gamma, delta, mu1, mu2)
-        oracle.affine_traceback(n, m, s, beta, gamma, delta, mu1, mu2, layers)
-        spent += time.perf_counter() - t0
-        cells += synth.cells_per_pair(n, m, s)
-        n_done += 1
-        if spent > budget_s:
-            break
-    return {"value": cells / spent / 1e9, "unit": "Gcells/s", "cores": 1, "kind": "port",
-            "sample": f"first {n_done} pairs of the workload (fill+traceback, {cells} cells, "
-                      f"{spent:.1f} s on one host core)"}
+    sa, sb, ta, tb = synth.protein_pair(seed, length)
+    p = dict(synth.PROTEIN_PARAMS, max_shift=s)
+    mu1, mu2 = oracle.mu_tables(sa, sb, ta, tb, p)  # input preparation, not timed
+    t0 = time.perf_counter()
+    _, layers = oracle.affine_fill(length, length, s, p["gap_opening_cost"], p["gap_cost"], p["shift_cost"], mu1, mu2)
+    oracle.affine_traceback(length, length, s, p["gap_opening_cost"], p["gap_cost"], p["shift_cost"], mu1, mu2, layers)
+    return time.perf_counter() - t0, synth.cells_per_pair(length, length, s)
+
+
+def cpu_baseline(length, s, seed0, budget_s=12.0):
+    """oracle/bialign_oracle.c (a literal C port of the reference recurrence, kind "port") on
+    the first pairs of the same workload: one host core, then one process per host core of
+    this box's share.  Runs before anything touches the GPU (the pool forks)."""
+    import multiprocessing as mp
+    from oracle import oracle
+    oracle.build()
+    spent, cells, n1 = 0.0, 0, 0
+    while spent < budget_s and n1 < 8:
+        dt, c = _oracle_pair((seed0 + n1, length, s))
+        spent += dt
+        cells += c
+        n1 += 1
+    one = cells / spent / 1e9
+    cores = min(len(os.sched_getaffinity(0)), int(os.environ.get("CPU_SHARE", 16)))
+    per_core = max(1, min(n1, 4))
+    jobs = [(seed0 + t, length, s) for t in range(cores * per_core)]
+    t0 = time.perf_counter()
+    with mp.get_context("fork").Pool(cores) as pool:
+        res = pool.map(_oracle_pair, jobs, chunksize=1)
+    wall = time.perf_counter() - t0
+    return {"value": one, "unit": "Gcells/s", "cores": 1, "kind": "port",
+            "sample": f"first {n1} pairs of the workload (fill+traceback, {cells} cells, {spent:.1f} s on one host core)",
+            "all_cores": {"value": sum(c for _, c in res) / wall / 1e9, "unit": "Gcells/s", "cores": cores,
+                          "sample": f"first {len(jobs)} pairs, one process per core, {wall:.1f} s wall"},
+            # the Cython reference itself cannot travel to this box; its rate was measured in the dev container
+            "reference_cython": {"value": 21e-6, "unit": "Gcells/s", "cores": 1, "measured_live": False,
+                                 "source": "BASELINE.md section 4.1 (tools/time_reference.py, len 128/256 pairs of this family)"}}
+
+
+def run_steps(batch, count, gather, npairs_total):
+    """count steps; -> (fill ms, traceback ms, fill launches) summed over them."""
+    acc = [0.0, 0.0, 0]
+    for _ in range(count):
+        batch.run()                      # fill + traceback, all chunks; returns when the device is done
+        gather(batch.scores(), npairs_total)  # the one collective (no-op at N=1)
+        t = batch.timing()               # HIP-event times recorded on the engine's stream
+        acc[0] += t["fill_ms"]; acc[1] += t["traceback_ms"]; acc[2] += t["fill_launches"]
+    return acc
+
+
+def roofline(info, fill_ms, launches, key):
+    fill_avg_ms = fill_ms / max(launches, 1)                  # average fill-kernel launch
+    bytes_per_launch = info["layer_bytes"] / info["nchunks"]  # 36 B x cells of one launch
+    achieved = bytes_per_launch / (fill_avg_ms * 1e-3) / 1e9
+    traffic, source = None, None
+    tpath = os.path.join(REPO, "profiles", "hbm_traffic.json")
+    if os.path.exists(tpath):  # PMC counters cannot be read from inside the run: per-launch bytes of the same
+        with open(tpath) as fh:  # launch shape from the committed rocprofv3 passes, with their directory
+            entry = json.load(fh).get(key)
+        if entry:
+            traffic, source = entry["bytes_per_launch"], entry["profile"]
+    return {"bound": "hbm", "kernel": "fill_affine_kernel", "achieved": achieved, "peak": HBM_PEAK_GBPS,
+            "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": source,
+            "bytes_per_launch": bytes_per_launch, "avg_launch_ms": fill_avg_ms}
 
 
 def main():
@@ -55,15 +110,13 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--pairs", type=int, default=1024, help="pairs per GPU")
-    ap.add_argument("--len", type=int, default=512, dest="length")
+    ap.add_argument("--len", type=int, default=1024, dest="length")
     ap.add_argument("--max_shift", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--streams", type=int, default=1,
-                    help="2 = two engines (HIP streams) with one resident batch each, steps enqueued alternately: the next "
-                         "step's sweep fills the SIMDs the current one's stragglers leave idle.  Per-launch kernel times "
-                         "(and the roofline object computed from them) are then those of overlapping launches.")
-    ap.add_argument("--reserve-tries", type=int, default=4,
-                    help="candidate placements of the layer buffer probed in setup (Engine.reserve); 1 = take the first")
+    ap.add_argument("--no-extra", action="store_true", help="skip the untimed config-2 block")
+    ap.add_argument("--reserve-tries", type=int, default=1,
+                    help="headline batch: candidate placements of the layer buffer probed in setup (Engine.reserve); "
+                         "needs twice the buffer in free HBM, i.e. not possible at the default workload")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -71,6 +124,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+
+    cpu = None
+    if world == 1 and not args.no_cpu_baseline:  # host cores only, before the GPU is initialised
+        cpu = cpu_baseline(args.length, args.max_shift, 1000)
 
     import torch
     import torch.distributed as dist
@@ -88,85 +145,40 @@ def main():
 
     from bialign_amd import synth
     from bialign_amd.batch import make_batch
+    from bialign_amd.distributed import gather_scores
     from bialign_amd.engine import Engine
 
     params = dict(synth.PROTEIN_PARAMS, max_shift=args.max_shift)
     pairs = synth.protein_batch(args.pairs, args.length, seed0=1000 + rank * args.pairs)
     engine = Engine(device)
-    batch = make_batch(pairs, params, engine=engine)  # inputs now resident in HBM
-    info = batch.info
+    budget = 0
+    if rehearse:  # ranks share one GPU's memory
+        budget = int(torch.cuda.mem_get_info(device)[0] * 0.8 / world)
     placement = {"reserve_tries": 1, "probe_gbps": None}
-    if args.reserve_tries > 1 and not rehearse:  # (rehearsal ranks share one GPU's memory)
-        # Setup, untimed: where the 83 GiB layer buffer lands physically decides 10-20 % of the fill time
-        # (profiles/r01e_placement); a long-running engine picks its buffer once (Engine.reserve) and keeps it.
-        batch.close()
+    if args.reserve_tries > 1 and not rehearse:
+        probe = make_batch(pairs, params, engine=engine)
+        need = probe.info["hbm_layer_bytes"] + 64
+        probe.close()
         try:
-            rate = engine.reserve(info["hbm_layer_bytes"] + 64, tries=args.reserve_tries)
-            placement = {"reserve_tries": args.reserve_tries, "probe_gbps": rate}
+            placement = {"reserve_tries": args.reserve_tries, "probe_gbps": engine.reserve(need, tries=args.reserve_tries)}
         except Exception as e:  # placement is an optimisation: never fail the run over it
-            placement = {"reserve_tries": 1, "probe_gbps": None, "reserve_error": str(e)[:200]}
-        batch = make_batch(pairs, params, engine=engine)  # takes the reserved buffer
-        info = batch.info
-    for _ in range(3):  # engine warm-up, not steps: the first launches load the code objects, touch the buffer's pages
-        batch.run()     # for the first time and ramp the clocks (the first two or three runs of a process are ~10 % slower)
-
-    lanes = [batch]  # --streams 2: a second engine + batch over the same pairs, steps alternate between them
-    if args.streams == 2:
-        engine2 = Engine(device)
-        if args.reserve_tries > 1 and not rehearse:
-            engine2.reserve(info["hbm_layer_bytes"] + 64, tries=args.reserve_tries)
-        lanes.append(make_batch(pairs, params, engine=engine2))
-        lanes[1].run()
+            placement["reserve_error"] = str(e)[:200]
+    batch = make_batch(pairs, params, engine=engine, hbm_budget_bytes=budget)  # inputs now resident in HBM
+    info = batch.info
+    for _ in range(2):  # engine warm-up, not steps: the first launches load the code objects, touch the buffer's pages
+        batch.run()     # for the first time and ramp the clocks
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    from bialign_amd.distributed import gather_scores
-
-    def step():
-        batch.run()                      # fill + traceback, all chunks; returns when the device is done
-        scores = batch.scores()          # int32[pairs] of this rank
-        # the one collective: all_gather of the scores over RCCL/xGMI (no-op at N=1)
-        return gather_scores(scores, args.pairs * world)
-
-    def steps_pipelined(count):
-        """count steps over two lanes: step k+1 is enqueued before step k's results are taken."""
-        acc = [0.0, 0.0, 0]
-        if count:
-            lanes[0].run(wait=False)
-        for k in range(count):
-            if k + 1 < count:
-                lanes[(k + 1) % 2].run(wait=False)
-            cur = lanes[k % 2]
-            gather_scores(cur.scores(), args.pairs * world)   # waits for step k
-            t = cur.timing()
-            acc[0] += t["fill_ms"]; acc[1] += t["traceback_ms"]; acc[2] += t["fill_launches"]
-        return acc
-
-    fill_ms = tb_ms = 0.0
-    launches = 0
-    if len(lanes) == 2:
-        steps_pipelined(args.warmup)
-        barrier()
-        t0 = time.perf_counter()
-        fill_ms, tb_ms, launches = steps_pipelined(args.steps)
-        barrier()
-        elapsed = time.perf_counter() - t0
-    else:
-        for _ in range(args.warmup):
-            step()
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
-            t = batch.timing()               # HIP-event times on the engine's stream
-            fill_ms += t["fill_ms"]
-            tb_ms += t["traceback_ms"]
-            launches += t["fill_launches"]
-        barrier()
-        elapsed = time.perf_counter() - t0
+    run_steps(batch, args.warmup, gather_scores, args.pairs * world)
+    barrier()
+    t0 = time.perf_counter()
+    fill_ms, tb_ms, launches = run_steps(batch, args.steps, gather_scores, args.pairs * world)
+    barrier()
+    elapsed = time.perf_counter() - t0
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -176,46 +188,74 @@ def main():
         total_cells, total_pairs = int(tot[0].item()), int(tot[1].item())
     else:
         total_cells, total_pairs = info["cells"], info["npairs"]
+    timing = batch.timing()
+    batch.close()
 
+    line = None
     if rank == 0:
-        ms_per_step = elapsed / args.steps * 1e3
-        fill_avg_ms = fill_ms / max(launches, 1)             # average fill-kernel launch
-        bytes_per_launch = info["layer_bytes"] / info["nchunks"]  # 36 B x cells of one launch
-        achieved = bytes_per_launch / (fill_avg_ms * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(REPO, "profiles", "hbm_traffic.json")
-        if os.path.exists(tpath):
-            with open(tpath) as fh:
-                traffic = json.load(fh).get(f"protein_{args.pairs}x{args.length}_s{args.max_shift}")
+        value = total_cells * args.steps / elapsed / 1e9
+        is_cfg5 = (args.pairs, args.length, args.max_shift) == (1024, 1024, 1)
         line = {
-            "metric": "giga-DP-cells/sec", "value": total_cells * args.steps / elapsed / 1e9,
+            "metric": "giga-DP-cells/sec", "value": value,
             "unit": "Gcells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             **({"rehearsal": "ranks share GPUs, gloo collectives: NOT a measurement"} if rehearse else {}),
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "int32", "data": "synthetic",
             "pairs_per_s": total_pairs * args.steps / elapsed,
-            "config": {"baseline_config": "BASELINE.json configs[1] per GPU" if (args.pairs, args.length, args.max_shift) == (1024, 512, 1)
-                                          else "custom (--pairs/--len/--max_shift)",
+            # the layer buffer of the headline is whatever hipMalloc returned (no placement probing)
+            **({"value_default_alloc": value} if placement["probe_gbps"] is None else {}),
+            "config": {"baseline_config": "BASELINE.json configs[4] per-GPU share (the metric's 1k x 1k, max_shift=1 workload)"
+                                          if is_cfg5 else "custom (--pairs/--len/--max_shift)",
                        "workload": f"{args.pairs} synthetic protein pairs per GPU, len {args.length}, "
                                    f"BLOSUM62, affine gaps (beta=-150, gamma=-50, Delta=-150, sw=800), "
                                    f"max_shift={args.max_shift}; fill + traceback + score gather",
                        "pairs_per_gpu": args.pairs, "len": args.length, "max_shift": args.max_shift,
                        "cells_per_gpu": info["cells"], "chunks_per_step": info["nchunks"],
-                       "sharding": f"pairs sharded over {world} rank(s), no data-path collective",
-                       "layer_buffer_placement": placement, "streams": args.streams},
+                       "layer_bytes_per_gpu": info["layer_bytes"], "hbm_layer_buffer_bytes": info["hbm_layer_bytes"],
+                       "waves_per_pair": timing["waves_per_pair"],
+                       "sharding": f"rank r owns pairs [r*{args.pairs}, (r+1)*{args.pairs}) of {args.pairs * world}; "
+                                   f"no data-path collective, one all_gather of int32 scores",
+                       "layer_buffer_placement": placement},
             "kernel_ms": {"fill": fill_ms / args.steps, "traceback": tb_ms / args.steps},
-            "roofline": {"bound": "hbm", "kernel": "fill_affine_kernel", "achieved": achieved,
-                         "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                         "traffic": traffic, "bytes_per_launch": bytes_per_launch,
-                         "avg_launch_ms": fill_avg_ms},
+            "roofline": roofline(info, fill_ms, launches, f"protein_{args.pairs}x{args.length}_s{args.max_shift}"),
         }
-        if not args.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline(pairs, params)
-        elif not args.no_cpu_baseline:
-            line["cpu_baseline"] = None  # measured at N=1 only
+        if not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu  # measured at N=1 only (None otherwise)
+
+    if rank == 0 and world == 1 and not args.no_extra and not rehearse:
+        # ---- untimed extra: BASELINE configs[1] (1024 pairs x len 512), first on the buffer the engine
+        # already holds (default allocation), then on a placement-probed one (profiles/r01e_placement)
+        c2pairs = synth.protein_batch(1024, 512, seed0=1000)
+        c2params = dict(synth.PROTEIN_PARAMS)
+        extra = {"workload": "BASELINE.json configs[1]: 1024 synthetic protein pairs, len 512, max_shift=1, affine"}
+        engine.trim()
+        for label, tries in (("default_alloc", 1), ("reserved", 4)):
+            b2 = make_batch(c2pairs, c2params, engine=engine)
+            i2 = b2.info
+            if tries > 1:
+                b2.close()
+                try:
+                    rate = engine.reserve(i2["hbm_layer_bytes"] + 64, tries=tries)
+                except Exception as e:
+                    extra[label] = {"error": str(e)[:200]}
+                    continue
+                b2 = make_batch(c2pairs, c2params, engine=engine)
+            for _ in range(3):
+                b2.run()
+            t1 = time.perf_counter()
+            f2, tb2, l2 = run_steps(b2, 5, gather_scores, 1024)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t1
+            extra[label] = {"value": i2["cells"] * 5 / dt / 1e9, "unit": "Gcells/s", "ms_per_step": dt / 5 * 1e3,
+                            "kernel_ms": {"fill": f2 / 5, "traceback": tb2 / 5},
+                            "roofline": roofline(i2, f2, l2, "protein_1024x512_s1"),
+                            **({"probe_gbps": rate, "reserve_tries": tries} if tries > 1 else {})}
+            b2.close()
+        line["extra"] = {"config2": extra}
+
+    if rank == 0:
         print(json.dumps(line), flush=True)
-    for lane in lanes:
-        lane.close()
+    engine.close()
     if world > 1:
         dist.destroy_process_group()
 

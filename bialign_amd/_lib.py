@@ -10,7 +10,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("BIALIGN_LIB_OVERRIDE") or os.path.join(HERE, "libbialign_hip.so")  # override: timing experiments only
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 RUN_FILL_ONLY = 1
 RUN_ASYNC = 2
 REC_AUTO, REC_AFFINE, REC_LINEAR = 0, 1, 2
@@ -54,7 +54,8 @@ class BatchInfo(ctypes.Structure):
 class Timing(ctypes.Structure):
     _fields_ = [("fill_ms", ctypes.c_double), ("traceback_ms", ctypes.c_double),
                 ("fill_launches", ctypes.c_int32), ("traceback_launches", ctypes.c_int32),
-                ("waves_per_pair", ctypes.c_int32), ("cross_cu", ctypes.c_int32)]
+                ("waves_per_pair", ctypes.c_int32), ("cross_cu", ctypes.c_int32),
+                ("recovered_runs", ctypes.c_int32), ("reserved", ctypes.c_int32)]
 
 
 #: every symbol include/bialign.h declares: (name, restype, argtypes)

@@ -31,8 +31,9 @@ int fail(int code, const char* fmt, ...) {
 //  * cross-CU teams (one-wave workgroups, progress words in HBM, write-through stores): up to 32
 //    waves per pair, used when even the largest in-workgroup team leaves most SIMDs idle (few,
 //    long pairs).  Every workgroup of the launch must be resident at once (a wave spins on its
-//    predecessor), so the grid is capped by the LDS-limited residency of the device.
-TeamShape team_shape(const bialign_batch* b, int first, int count) {
+//    predecessor), so the grid is capped by the residency the runtime's occupancy calculation gives
+//    for the actual kernel (xcu_resident; 0 = cross-CU teams not available for this launch).
+TeamShape team_shape(const bialign_batch* b, int first, int count, int xcu_resident) {
   TeamShape ts;
   const int W = 2 * b->S + 1, R = 64 / W;
   const int lag = 2 * (R - 1) + 2 * ghost_blk(b->S) + 16;
@@ -47,15 +48,10 @@ TeamShape team_shape(const bialign_batch* b, int first, int count) {
   // the one-layer (non-affine) kernel is small in registers at every s
   int tw = std::min(fit, !b->affine ? 8 : (b->S <= 1 ? 8 : (b->S <= 3 ? 4 : 1)));
   while (tw > 1 && b->lds_base + (size_t)tw * b->lds_per_wave > 160 * 1024) tw >>= 1;
-  // one-wave workgroups resident per CU (LDS-limited; allocation granularity 1 KiB)
-  const size_t lds1 = (b->lds_base + b->lds_per_wave + 1023) / 1024 * 1024;
-  // ... and register-limited: the s<=2 kernels allow >= 2 waves per SIMD, s=3 one wave per SIMD
-  const size_t by_regs = b->S <= 2 ? 8 : 4;
-  const int resident = b->eng->num_cu * (int)std::min<size_t>(by_regs, (160 * 1024) / lds1);
   if (b->dense) tw = std::min(tw, 2);  // dense-mu2 kernels are instantiated for 1 and 2 waves
   // cross-CU teams (affine LOOKUP kernels only) take any size: the team is a runtime value there
-  int gw = (b->affine && b->S <= 3 && !b->dense) ? fit_exact : 1;
-  gw = std::max(1, std::min(gw, resident / std::max(count, 1)));
+  int gw = (b->affine && b->S <= 3 && !b->dense && xcu_resident > 0) ? fit_exact : 1;
+  gw = std::max(1, std::min(gw, xcu_resident / std::max(count, 1)));
 
   const char* e = getenv("BIALIGN_TEAM");  // experiments / tests: "N" in-workgroup, "xN" cross-CU
   if (e && e[0] == 'x') {
@@ -94,6 +90,32 @@ TeamShape team_shape(const bialign_batch* b, int first, int count) {
     if (g >= 2 * t || (t == 8 && g >= 8 && count * 8 <= b->eng->num_cu)) { ts.tw = 1; ts.gw = g; }
   }
   return ts;
+}
+
+// ---- cross-CU launches, one at a time per device (all engines of the process)
+static std::mutex g_xcu_mu;
+static hipEvent_t g_xcu_done[64] = {};  // per device: the last cross-CU launch (never destroyed: process lifetime)
+
+int xcu_serial_begin(bialign_engine* e) {
+  g_xcu_mu.lock();  // held until xcu_serial_end: wait, launch and record are one step
+  if (getenv("BIALIGN_XCU_NOSERIAL")) return BIALIGN_OK;  // tests: provoke lost co-residency
+  hipEvent_t& ev = g_xcu_done[e->device & 63];
+  hipError_t err = hipSuccess;
+  if (!ev) err = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+  else err = hipStreamWaitEvent(e->stream, ev, 0);
+  if (err != hipSuccess) {
+    g_xcu_mu.unlock();
+    return fail(BIALIGN_E_DEVICE, "cross-CU launch ordering: %s", hipGetErrorString(err));
+  }
+  return BIALIGN_OK;
+}
+
+int xcu_serial_end(bialign_engine* e) {
+  hipError_t err = hipSuccess;
+  if (!getenv("BIALIGN_XCU_NOSERIAL")) err = hipEventRecord(g_xcu_done[e->device & 63], e->stream);
+  g_xcu_mu.unlock();
+  if (err != hipSuccess) return fail(BIALIGN_E_DEVICE, "cross-CU launch ordering: %s", hipGetErrorString(err));
+  return BIALIGN_OK;
 }
 
 }  // namespace bialign
@@ -476,6 +498,7 @@ int bialign_batch_create(bialign_engine* eng, const bialign_params* prm, const b
   HIP_TRY(b->d_complete.alloc(pr->npairs));
   HIP_TRY(b->d_err.alloc(1));
   HIP_TRY(hipMemsetAsync(b->d_err.p, 0, sizeof(int32_t), st));
+  if (const char* e = getenv("BIALIGN_XCU_SPIN_LIMIT")) b->xcu_spin_limit = std::max(0, atoi(e));  // tests: force hand-off timeouts
   HIP_TRY(b->d_trace.alloc(b->trace_bytes));
   HIP_TRY(hipMemsetAsync(b->d_tlen.p, 0, sizeof(int32_t) * pr->npairs, st));
   HIP_TRY(hipMemsetAsync(b->d_complete.p, 0, sizeof(int32_t) * pr->npairs, st));
@@ -572,37 +595,15 @@ int bialign_batch_get_info(const bialign_batch* b, bialign_batch_info* info) {
   return BIALIGN_OK;
 }
 
-int bialign_batch_wait(bialign_batch* b) {
-  if (!b) return fail(BIALIGN_E_INVALID, "NULL batch");
-  if (!b->pending) return BIALIGN_OK;
-  HIP_TRY(hipSetDevice(b->eng->device));
-  b->pending = false;
-  HIP_TRY(hipEventSynchronize(b->evs.back()));
-  const int nchunks = (int)b->chunk_begin.size() - 1;
-  for (int c = 0; c < nchunks; ++c) {
-    float f = 0, t = 0;
-    HIP_TRY(hipEventElapsedTime(&f, b->evs[3 * c], b->evs[3 * c + 1]));
-    HIP_TRY(hipEventElapsedTime(&t, b->evs[3 * c + 1], b->evs[3 * c + 2]));
-    b->timing.fill_ms += f;
-    b->timing.traceback_ms += t;
-  }
-  int rc_err = check_device_error(b);
-  if (rc_err) return rc_err;
-  b->ran = true;
-  b->ran_trace = b->pending_trace;
-  return BIALIGN_OK;
-}
-
-int bialign_batch_run(bialign_batch* b, uint32_t flags) {
-  if (!b) return fail(BIALIGN_E_INVALID, "NULL batch");
-  int rc = bialign_batch_wait(b);  // one run of a batch at a time
-  if (rc) return rc;
+// Enqueue one run of the batch on the engine's stream (all chunks: fill, then traceback).
+static int enqueue_run(bialign_batch* b, uint32_t flags) {
   HIP_TRY(hipSetDevice(b->eng->device));
   const bool do_trace = !(flags & BIALIGN_RUN_FILL_ONLY) && (!b->lean || b->lean_trace);
   const DeviceBatch v = b->view();
   hipStream_t st = b->eng->stream;
   b->timing = bialign_timing{};
   b->ran = b->ran_trace = false;
+  b->used_xcu = false;
   const int nchunks = (int)b->chunk_begin.size() - 1;
   while ((int)b->evs.size() < 3 * nchunks) {
     hipEvent_t e = nullptr;
@@ -610,10 +611,11 @@ int bialign_batch_run(bialign_batch* b, uint32_t flags) {
     b->evs.push_back(e);
   }
   HIP_TRY(hipStreamWaitEvent(st, b->uploaded, 0));
+  HIP_TRY(hipMemsetAsync(b->d_err.p, 0, sizeof(int32_t), st));  // the flag is per run
   for (int c = 0; c < nchunks; ++c) {  // stream order keeps chunk c's traceback ahead of chunk c+1's sweep
     const int first = b->chunk_begin[c], count = b->chunk_begin[c + 1] - first;
     HIP_TRY(hipEventRecord(b->evs[3 * c], st));
-    rc = launch_fill(b, v, first, count);
+    int rc = launch_fill(b, v, first, count);
     if (rc) return rc;
     HIP_TRY(hipEventRecord(b->evs[3 * c + 1], st));
     if (!b->lean) {  // (with LEAN records the sweep itself wrote the scores)
@@ -631,6 +633,49 @@ int bialign_batch_run(bialign_batch* b, uint32_t flags) {
   }
   b->pending = true;
   b->pending_trace = do_trace;
+  b->pending_flags = flags;
+  return BIALIGN_OK;
+}
+
+int bialign_batch_wait(bialign_batch* b) {
+  if (!b) return fail(BIALIGN_E_INVALID, "NULL batch");
+  if (!b->pending) return BIALIGN_OK;
+  HIP_TRY(hipSetDevice(b->eng->device));
+  for (;;) {
+    b->pending = false;
+    HIP_TRY(hipEventSynchronize(b->evs.back()));
+    const int nchunks = (int)b->chunk_begin.size() - 1;
+    for (int c = 0; c < nchunks; ++c) {
+      float f = 0, t = 0;
+      HIP_TRY(hipEventElapsedTime(&f, b->evs[3 * c], b->evs[3 * c + 1]));
+      HIP_TRY(hipEventElapsedTime(&t, b->evs[3 * c + 1], b->evs[3 * c + 2]));
+      b->timing.fill_ms += f;
+      b->timing.traceback_ms += t;
+    }
+    int32_t err = 0;
+    HIP_TRY(hipMemcpy(&err, b->d_err.p, sizeof err, hipMemcpyDeviceToHost));
+    if (!err) break;
+    // A cross-CU team lost co-residency (its waves spin on partners that were never scheduled:
+    // another tenant holds wave slots).  The run is repeated once with in-workgroup teams, which
+    // depend on nobody; the batch stays on them.
+    if (!b->used_xcu || b->no_xcu)
+      return fail(BIALIGN_E_DEVICE, "fill kernel: team hand-off timed out (device error flag %d)", err);
+    b->no_xcu = true;
+    ++b->recovered;
+    if (int rc = enqueue_run(b, b->pending_flags)) return rc;
+  }
+  b->timing.recovered_runs = b->recovered;
+  b->ran = true;
+  b->ran_trace = b->pending_trace;
+  return BIALIGN_OK;
+}
+
+int bialign_batch_run(bialign_batch* b, uint32_t flags) {
+  if (!b) return fail(BIALIGN_E_INVALID, "NULL batch");
+  int rc = bialign_batch_wait(b);  // one run of a batch at a time
+  if (rc) return rc;
+  rc = enqueue_run(b, flags);
+  if (rc) return rc;
   return (flags & BIALIGN_RUN_ASYNC) ? BIALIGN_OK : bialign_batch_wait(b);
 }
 
@@ -675,8 +720,20 @@ int bialign_batch_dump_layers(bialign_batch* b, int32_t pair, int32_t* out) {
   // one-pair launch out of the regular launch order (team shape and layer offset are the pair's own)
   const int pos = (int)(std::find(b->order.begin(), b->order.end(), pair) - b->order.begin());
   DeviceBatch v = b->view();
+  HIP_TRY(hipMemsetAsync(b->d_err.p, 0, sizeof(int32_t), st));
+  b->used_xcu = false;
   int rc = launch_fill(b, v, pos, 1);
   if (rc) return rc;
+  if (b->used_xcu && !b->no_xcu) {  // a cross-CU team that lost co-residency: once more, in one workgroup
+    HIP_TRY(hipStreamSynchronize(st));
+    if (check_device_error(b) != BIALIGN_OK) {
+      b->no_xcu = true;
+      ++b->recovered;
+      HIP_TRY(hipMemsetAsync(b->d_err.p, 0, sizeof(int32_t), st));
+      rc = launch_fill(b, v, pos, 1);
+      if (rc) return rc;
+    }
+  }
   const PairDesc& d = b->pairs[pair];
   const int W = 2 * b->S + 1;
   const size_t elems = (size_t)b->NL * (d.n + 1) * (d.m + 1) * W * W;

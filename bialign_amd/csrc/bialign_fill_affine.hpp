@@ -213,7 +213,7 @@ __global__ void __launch_bounds__(64 * TW) fill_affine_kernel(const DeviceBatch 
     if (seen_prog >= need) return;
     // bounded spin: a protocol bug must surface as an error, never as a hung GPU
     for (int spin = 0; (seen_prog = prog_get(src)) < need; ++spin) {
-      if (spin > (1 << 20)) {  // ~0.5 s; then fail fast: no further waits, host reports the error
+      if (spin > A.spin_limit) {  // ~1 s by default; then fail fast: no further waits, the host recovers or reports
         if (L == 0) atomicExch(A.errflag, 1);
         team_failed = true;
         break;

@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <numeric>
 #include <string>
 #include <vector>
@@ -103,6 +104,16 @@ struct bialign_batch {
   DevBuf<PairDesc> d_pairs;
   DevBuf<int32_t> d_order, d_s1, d_s2, d_layers, d_scores, d_tlen, d_complete, d_err, d_prog;
   int last_team = 1;  // waves per pair of the last fill launch (negative: cross-CU team)
+  // Cross-CU teams need every workgroup of the launch resident at once.  The grid is sized from the
+  // occupancy the runtime reports for the actual kernel (xcu_resident, cached per LEAN flavour) and
+  // launches of this kind are serialised across the engines of a process; if a hand-off still times
+  // out (another tenant on the device), the run is repeated with in-workgroup teams (no_xcu).
+  int xcu_resident[2] = {-1, -1};
+  bool used_xcu = false;   // a fill launch of the pending / last run was a cross-CU team
+  bool no_xcu = false;     // a cross-CU launch of this batch failed once: in-workgroup teams from now on
+  int recovered = 0;       // runs repeated after a hand-off timeout
+  int xcu_spin_limit = 1 << 20;  // polls before a cross-CU wave gives up (~1 s); BIALIGN_XCU_SPIN_LIMIT: tests
+  uint32_t pending_flags = 0;
   DevBuf<uint8_t> d_seq_a, d_cls_a, d_seq_b, d_cls_b, d_trace;
   DevBuf<int32_t> d_mu2;  // dense-mu2 mode: all pairs' n x m tables
   bool dense = false;
@@ -140,6 +151,7 @@ struct bialign_batch {
     v.scratch = d_layers.p;  // a pair's scratch records follow its LEAN records in the same buffer
     v.tstate = d_tstate.p;
     v.resw_k = resw_k;
+    v.spin_limit = 1 << 20;  // waves of one workgroup are co-resident by construction: a timeout there is a bug
     return v;
   }
 };
@@ -152,7 +164,12 @@ struct TeamShape {
   int waves() const { return tw * gw; }
 };
 
-TeamShape team_shape(const bialign_batch* b, int first, int count);
+// xcu_resident: one-wave workgroups of the cross-CU kernel the device holds at once (0: no such kernel)
+TeamShape team_shape(const bialign_batch* b, int first, int count, int xcu_resident);
+// Cross-CU launches of all engines of this process on one device run one after the other (each needs
+// the whole device's wave slots): the stream waits for the previous such launch, the new one is recorded.
+int xcu_serial_begin(bialign_engine* e);
+int xcu_serial_end(bialign_engine* e);
 
 template <int S, bool BETA_NONPOS, int TW, bool XCU, bool DENSE = false, bool LEAN = false>
 int launch_fill_affine_t(bialign_batch* b, const DeviceBatch& v, int first, int count, int gw) {
@@ -168,10 +185,43 @@ int launch_fill_affine_t(bialign_batch* b, const DeviceBatch& v, int first, int 
     if (b->d_prog.n < (size_t)count * 64) HIP_TRY(b->d_prog.alloc((size_t)count * 64));
     HIP_TRY(hipMemsetAsync(b->d_prog.p, 0, (size_t)count * 64 * sizeof(int32_t), b->eng->stream));
     w.prog = b->d_prog.p;
+    w.spin_limit = b->xcu_spin_limit;
+    b->used_xcu = true;
+    if (int rc = xcu_serial_begin(b->eng)) return rc;
   }
   hipLaunchKernelGGL(kern, dim3(count * (XCU ? gw : 1)), dim3(64 * TW), lds, b->eng->stream, w);
-  HIP_TRY(hipGetLastError());
+  const hipError_t launched = hipGetLastError();
+  if (XCU) {
+    const int rc = xcu_serial_end(b->eng);  // always: it releases the launch lock
+    if (launched == hipSuccess && rc) return rc;
+  }
+  HIP_TRY(launched);
   return BIALIGN_OK;
+}
+
+// One-wave workgroups of the cross-CU kernel <S, LEAN> the device can hold at once, from the runtime's
+// occupancy calculation for the actual code object (registers, LDS): the cap of a cross-CU grid.
+template <int S, bool LEAN>
+int xcu_resident_blocks(bialign_batch* b) {
+  int& cached = b->xcu_resident[LEAN ? 1 : 0];
+  if (cached >= 0) return cached;
+  cached = 0;
+  if constexpr (S <= 3) {
+    auto kern = fill_affine_kernel<S, true, 1, true, false, LEAN>;
+    const size_t lds = b->lds_base + b->lds_per_wave;
+    if (lds > 64 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+      (void)hipGetLastError();
+      return cached;
+    }
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), 64, lds) != hipSuccess) {
+      (void)hipGetLastError();
+      return cached;
+    }
+    cached = per_cu * b->eng->num_cu;
+  }
+  return cached;
 }
 
 template <int S, bool LEAN>
@@ -181,7 +231,8 @@ int launch_fill_affine_l(bialign_batch* b, const DeviceBatch& v, int first, int 
     return b->dense ? launch_fill_affine_t<S, false, 1, false, true, LEAN>(b, v, first, count, 1)
                     : launch_fill_affine_t<S, false, 1, false, false, LEAN>(b, v, first, count, 1);
   }
-  const TeamShape ts = team_shape(b, first, count);
+  const bool xcu_ok = !b->dense && !b->no_xcu;
+  const TeamShape ts = team_shape(b, first, count, xcu_ok ? xcu_resident_blocks<S, LEAN>(b) : 0);
   b->last_team = ts.waves() * (ts.gw > 1 ? -1 : 1);
   if (b->dense) {
     if constexpr (S <= 3) {
@@ -277,7 +328,7 @@ int launch_fill_linear_t(bialign_batch* b, const DeviceBatch& v, int first, int 
 
 template <int S, bool LEAN>
 int launch_fill_linear_l(bialign_batch* b, const DeviceBatch& v, int first, int count) {
-  const TeamShape ts = team_shape(b, first, count);
+  const TeamShape ts = team_shape(b, first, count, 0);
   b->last_team = ts.tw;
   if (b->dense)
     return ts.tw >= 2 ? launch_fill_linear_t<S, 2, true, LEAN>(b, v, first, count)

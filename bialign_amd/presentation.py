@@ -17,7 +17,8 @@ def _host_lib():
     """libbialign_host.so (bialign_amd/csrc/bialign_host.c, built by bialign_amd.build)."""
     global _HOST_LIB
     if _HOST_LIB is None:
-        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libbialign_host.so")
+        path = os.environ.get("BIALIGN_HOST_LIB_OVERRIDE") or \
+            os.path.join(os.path.dirname(os.path.abspath(__file__)), "libbialign_host.so")  # override: sanitizer build (tests)
         if not os.path.exists(path):
             raise ImportError(f"{path} not found: run python -m bialign_amd.build")
         lib = ctypes.CDLL(path)

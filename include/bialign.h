@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define BIALIGN_ABI_VERSION 7
+#define BIALIGN_ABI_VERSION 8
 
 #define BIALIGN_OK 0
 #define BIALIGN_E_INVALID (-1)     /* bad argument (message says which) */
@@ -127,6 +127,9 @@ typedef struct bialign_timing {
   int32_t traceback_launches;
   int32_t waves_per_pair; /* team size of the last fill launch (team sweep) */
   int32_t cross_cu;       /* 1 if that team was spread over one-wave workgroups */
+  int32_t recovered_runs; /* runs of this batch repeated with in-workgroup teams after a cross-CU team lost
+                             co-residency (another tenant on the device); the results are those of the repeat */
+  int32_t reserved;
 } bialign_timing;
 
 int bialign_abi_version(void);
