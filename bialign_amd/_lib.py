@@ -14,7 +14,8 @@ ABI_VERSION = 8
 RUN_FILL_ONLY = 1
 RUN_ASYNC = 2
 REC_AUTO, REC_AFFINE, REC_LINEAR = 0, 1, 2
-MAX_SHIFT = 5
+MAX_SHIFT = 1024       # BIALIGN_MAX_SHIFT
+MAX_SHIFT_TILED = 5    # BIALIGN_MAX_SHIFT_TILED: wider bands take the anti-diagonal path
 
 E_INVALID, E_UNSUPPORTED, E_DEVICE, E_NOMEM, E_RANGE = -1, -2, -3, -4, -5
 

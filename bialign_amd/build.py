@@ -33,6 +33,7 @@ def units():
            for s in range(MAX_SHIFT, -1, -1)]
     out += [(f"inst_s{s}_k1.o", "bialign_inst.hip", [f"-DBIALIGN_TU_S={s}", "-DBIALIGN_TU_KIND=1"])
             for s in range(MAX_SHIFT, -1, -1)]
+    out.append(("wide.o", "bialign_wide.hip", []))
     out.append(("capi.o", "bialign_capi.hip", []))
     return out
 

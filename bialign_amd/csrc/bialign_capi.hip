@@ -153,6 +153,7 @@ size_t lds_need(int S, int NL, int team, int k1, int k2, int n, int m, bool dens
 }
 
 int launch_fill(bialign_batch* b, const DeviceBatch& v, int first, int count) {
+  if (b->wide) return launch_fill_wide(b, v, first, count);
   if (b->affine) {
     switch (b->S) {
       case 0: return launch_fill_affine<0>(b, v, first, count);
@@ -201,6 +202,7 @@ int lean_traceback_rounds(bialign_batch* b, const DeviceBatch& v, int first, int
 }
 
 int launch_traceback(const bialign_batch* b, const DeviceBatch& v, int first, int count, bool do_trace) {
+  if (b->wide) return launch_traceback_wide(b, v, first, count, do_trace);
   if (b->affine) {
     switch (b->S) {
       case 0: return launch_traceback_affine<0>(b, v, first, count, do_trace);
@@ -224,6 +226,7 @@ int launch_traceback(const bialign_batch* b, const DeviceBatch& v, int first, in
 }
 
 int launch_dump_any(const bialign_batch* b, const DeviceBatch& v, int pid, int32_t* d_out) {
+  if (b->wide) return launch_dump_wide(b, v, pid, d_out);
   if (b->affine) {
     switch (b->S) {
       case 0: return launch_dump<0, 9>(b, v, pid, d_out);
@@ -315,8 +318,7 @@ int bialign_batch_create(bialign_engine* eng, const bialign_params* prm, const b
   if (pr->npairs < 1) return fail(BIALIGN_E_INVALID, "npairs must be >= 1");
   if (prm->max_shift < 0) return fail(BIALIGN_E_INVALID, "max_shift must be >= 0");
   if (prm->max_shift > BIALIGN_MAX_SHIFT)
-    return fail(BIALIGN_E_UNSUPPORTED, "max_shift %d > %d is not instantiated in this build", prm->max_shift,
-                BIALIGN_MAX_SHIFT);
+    return fail(BIALIGN_E_UNSUPPORTED, "max_shift %d > %d", prm->max_shift, BIALIGN_MAX_SHIFT);
   if (sc->k1 < 1 || sc->k1 > 256 || sc->k2 < 1 || sc->k2 > 256 || !sc->s1 || !sc->s2)
     return fail(BIALIGN_E_INVALID, "scoring tables: k1,k2 must be 1..256 and tables non-NULL");
   HIP_TRY(hipSetDevice(eng->device));
@@ -336,6 +338,10 @@ int bialign_batch_create(bialign_engine* eng, const bialign_params* prm, const b
   b->dense = pr->mu2_dense != nullptr;
   b->lean_trace = (prm->flags & BIALIGN_BATCH_LEAN_TRACE) != 0;
   b->lean = b->lean_trace || (prm->flags & BIALIGN_BATCH_SCORE_ONLY) != 0;
+  b->wide = prm->max_shift > BIALIGN_MAX_SHIFT_TILED;  // bialign_wide.hpp: anti-diagonal path, all layers in HBM
+  if (b->wide && b->lean)
+    return fail(BIALIGN_E_UNSUPPORTED, "reduced layer storage (SCORE_ONLY / LEAN_TRACE) exists for max_shift <= %d only",
+                BIALIGN_MAX_SHIFT_TILED);
   if (b->dense && !pr->mu2_off) return fail(BIALIGN_E_INVALID, "mu2_dense given without mu2_off");
   if (!b->dense && (!pr->cls_a || !pr->cls_b)) return fail(BIALIGN_E_INVALID, "cls_a / cls_b are NULL (LOOKUP form)");
   const int S = b->S, W = 2 * S + 1;
@@ -370,7 +376,8 @@ int bialign_batch_create(bialign_engine* eng, const bialign_params* prm, const b
     PairDesc& d = b->pairs[p];
     d.n = n;
     d.m = m;
-    sweep_geometry(n, m, S, &d.NS, &d.P, &d.G);
+    d.NS = d.P = d.G = 0;
+    if (!b->wide) sweep_geometry(n, m, S, &d.NS, &d.P, &d.G);
     d.trace_cap = 2 * (n + m) + 2;
     d.seq_a = pr->off_a[p];
     d.seq_b = pr->off_b[p];
@@ -381,14 +388,18 @@ int bialign_batch_create(bialign_engine* eng, const bialign_params* prm, const b
     b->cells += cells_of(n, m, S);
     tot_a = std::max<int64_t>(tot_a, pr->off_a[p] + n);
     tot_b = std::max<int64_t>(tot_b, pr->off_b[p] + m);
-    b->lds_bytes = std::max(b->lds_bytes, lds_need(S, b->NL, 1, sc->k1, sc->k2, n, m, b->dense));
-    b->lds_base = std::max(b->lds_base, lds_need(S, b->NL, 0, sc->k1, sc->k2, n, m, b->dense));
+    if (!b->wide) {
+      b->lds_bytes = std::max(b->lds_bytes, lds_need(S, b->NL, 1, sc->k1, sc->k2, n, m, b->dense));
+      b->lds_base = std::max(b->lds_base, lds_need(S, b->NL, 0, sc->k1, sc->k2, n, m, b->dense));
+    }
     b->lds_trace = std::max<size_t>(b->lds_trace, ((size_t)sc->k1 * sc->k1 + (size_t)sc->k2 * sc->k2) * 4 +
                                                       2 * (size_t)((n + 3) & ~3) + 2 * (size_t)((m + 3) & ~3));
   }
-  b->lds_per_wave = lds_need(S, b->NL, 1, sc->k1, sc->k2, 1, 1, b->dense) - lds_need(S, b->NL, 0, sc->k1, sc->k2, 1, 1, b->dense);
-  if (b->lds_bytes > 160 * 1024)
-    return fail(BIALIGN_E_UNSUPPORTED, "molecules too long for the LDS staging (%zu bytes needed)", b->lds_bytes);
+  if (!b->wide)
+    b->lds_per_wave = lds_need(S, b->NL, 1, sc->k1, sc->k2, 1, 1, b->dense) - lds_need(S, b->NL, 0, sc->k1, sc->k2, 1, 1, b->dense);
+  if (std::max(b->lds_bytes, b->lds_trace) > 160 * 1024)
+    return fail(BIALIGN_E_UNSUPPORTED, "molecules too long for the LDS staging (%zu bytes needed, 160 KiB per workgroup)",
+                std::max(b->lds_bytes, b->lds_trace));
 
   // ---- chunking under the HBM budget; inside a chunk longest sweeps first
   size_t free_b = 0, total_b = 0;
@@ -401,6 +412,10 @@ int bialign_batch_create(bialign_engine* eng, const bialign_params* prm, const b
   auto size_pairs = [&]() {
     for (int p = 0; p < pr->npairs; ++p) {
       PairDesc& d = b->pairs[p];
+      if (b->wide) {  // reference-order layers, every band slot of every (i, j)
+        pair_dwords[p] = wide_pair_dwords(d.n, d.m, S, b->NL);
+        continue;
+      }
       int slp = (64 / W - 1) * W;  // Rec<S,NL>::SLP
       if ((slp + 7) / 8 * 8 - slp <= BIALIGN_PADMAX) slp = (slp + 7) / 8 * 8;
       const int64_t full_rec = (int64_t)((b->NL * W) / 4) * slp * 4 + 64 * ((b->NL * W) % 4);  // Rec<S,NL>::RECDW per step
@@ -421,7 +436,7 @@ int bialign_batch_create(bialign_engine* eng, const bialign_params* prm, const b
   size_pairs();
   // A pair whose full layers exceed the budget is served from reduced storage instead of failing
   // (memory-lean traceback, ~1.3x the time).
-  if (!b->lean &&
+  if (!b->lean && !b->wide &&
       *std::max_element(pair_dwords.begin(), pair_dwords.end()) > budget_dw) {
     b->lean = b->lean_trace = true;
     pick_resw_k();
@@ -454,7 +469,10 @@ int bialign_batch_create(bialign_engine* eng, const bialign_params* prm, const b
   b->chunk_begin.push_back(pr->npairs);
   for (size_t c = 0; c + 1 < b->chunk_begin.size(); ++c)
     std::stable_sort(b->order.begin() + b->chunk_begin[c], b->order.begin() + b->chunk_begin[c + 1],
-                     [&](int x, int y) { return b->pairs[x].G > b->pairs[y].G; });
+                     [&](int x, int y) {
+                       return b->wide ? b->pairs[x].n + b->pairs[x].m > b->pairs[y].n + b->pairs[y].m  // levels
+                                      : b->pairs[x].G > b->pairs[y].G;
+                     });
 
   // ---- upload (own stream: a batch can be prepared while another one sweeps)
   hipStream_t st = eng->copy_stream;

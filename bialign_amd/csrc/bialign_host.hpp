@@ -117,6 +117,7 @@ struct bialign_batch {
   DevBuf<uint8_t> d_seq_a, d_cls_a, d_seq_b, d_cls_b, d_trace;
   DevBuf<int32_t> d_mu2;  // dense-mu2 mode: all pairs' n x m tables
   bool dense = false;
+  bool wide = false;        // max_shift above the tiled kernels: anti-diagonal path (bialign_wide.hpp), reference-order layers
   bool lean = false;        // LEAN records: the sweep keeps only the strip-bottom rows
   bool lean_trace = false;  // ... and tracebacks re-sweep one strip at a time into a scratch area
   DevBuf<TraceState> d_tstate;
@@ -151,6 +152,7 @@ struct bialign_batch {
     v.scratch = d_layers.p;  // a pair's scratch records follow its LEAN records in the same buffer
     v.tstate = d_tstate.p;
     v.resw_k = resw_k;
+    v.wide_s = S;
     v.spin_limit = 1 << 20;  // waves of one workgroup are co-resident by construction: a timeout there is a bug
     return v;
   }
@@ -398,6 +400,12 @@ int launch_dump(const bialign_batch* b, const DeviceBatch& v, int pid, int32_t* 
   HIP_TRY(hipGetLastError());
   return BIALIGN_OK;
 }
+
+// ---- wide-band path (max_shift above BIALIGN_MAX_SHIFT_TILED, bialign_wide.hpp): runtime band width,
+//      one translation unit (bialign_wide.hip) for all of it
+int launch_fill_wide(bialign_batch* b, const DeviceBatch& v, int first, int count);
+int launch_traceback_wide(const bialign_batch* b, const DeviceBatch& v, int first, int count, bool do_trace);
+int launch_dump_wide(const bialign_batch* b, const DeviceBatch& v, int pid, int32_t* d_out);
 
 // ---- instantiation plan: kind 0 = affine fill (the big kernels), kind 1 = everything else
 #define BIALIGN_INST_KIND0(S, X)                                                                \

@@ -53,5 +53,6 @@
 #include "bialign_feed.hpp"
 #include "bialign_fill_affine.hpp"
 #include "bialign_fill_linear.hpp"
+#include "bialign_wide.hpp"
 #include "bialign_traceback.hpp"
 #include "bialign_dump.hpp"

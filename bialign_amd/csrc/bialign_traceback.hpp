@@ -59,8 +59,12 @@ __device__ __forceinline__ int wave_min16(int v) {  // min over lanes 0..15, val
 //   TraceState through ONE strip -- the one fill_affine_kernel<.., RESW> has just re-swept into
 //   the scratch records -- and stops when it steps into the strip above (whose bottom row, the
 //   only row of it a candidate can touch from here, is in the LEAN records) or ends.
-template <int S, bool DO_TRACE, bool STRIP = false>
+//   WIDE (max_shift beyond the tiled kernels, bialign_wide.hpp): the band half-width is the runtime
+//   value A.wide_s and the layers lie in the reference's own order; S is then a dummy (0).
+template <int S, bool DO_TRACE, bool STRIP = false, bool WIDE = false>
 __global__ void __launch_bounds__(64) traceback_affine_kernel(const DeviceBatch A, int npairs) {
+  static_assert(!WIDE || !STRIP, "no lean traceback on the wide-band path");
+  const int SR = WIDE ? A.wide_s : S;  // band half-width
   const int pid = A.order[blockIdx.x];
   const PairDesc pd = A.pairs[pid];
   const int n = pd.n, m = pd.m;
@@ -81,6 +85,7 @@ __global__ void __launch_bounds__(64) traceback_affine_kernel(const DeviceBatch 
   const int64_t sstride = (int64_t)(m + Geo<S>::MAXOFF + 1) * Rec<S, 9>::RECDW;
   // layer value (state ss) of lattice point (pi, pj, a, b)
   auto cell = [&](int pi, int pj, int a, int b, int ss) -> int {
+    if (WIDE) return lay[pd.layer_off + wide_dword(m, 2 * SR + 1, 9, pi, pj, a, b, ss)];
     if (!STRIP) return lay[cell_dword<S, 9>(pd, pi, pj, a, b, ss)];
     const int sp = pi / RR, ilp = pi - sp * RR + 1;
     if (sp >= Qlo)  // inside a re-swept strip: record = step within the strip
@@ -94,7 +99,7 @@ __global__ void __launch_bounds__(64) traceback_affine_kernel(const DeviceBatch 
   int st = 0, cur = 0;
   if (!STRIP || !ts.started) {
     // pyx:573-582: best end layer, first one with the least shift
-    const int endv = c < 9 ? cell(n, m, S, S, c) : -BIG;
+    const int endv = c < 9 ? cell(n, m, SR, SR, c) : -BIG;
     const int best = __builtin_amdgcn_readfirstlane(-wave_min16(-endv));
     if (c == 0) A.scores[pid] = best;
     if (!DO_TRACE) return;
@@ -134,9 +139,9 @@ __global__ void __launch_bounds__(64) traceback_affine_kernel(const DeviceBatch 
                    : grp == 2 ? delta * (v0 + v1) + valV + openV
                               : delta * (u0 + u1) + valU + openU;
     const int pi = i - o0, pj = j - o1, pk = k - o2, pl = l - o3;
-    const bool ok = c < 15 && pi >= 0 && pj >= 0 && pk >= 0 && pl >= 0 && abs(pk - pi) <= S &&
-                    abs(pl - pj) <= S;  // pyx:133-141
-    const int ld = ok ? cell(pi, pj, pk - pi + S, pl - pj + S, ss) : 0;
+    const bool ok = c < 15 && pi >= 0 && pj >= 0 && pk >= 0 && pl >= 0 && abs(pk - pi) <= SR &&
+                    abs(pl - pj) <= SR;  // pyx:133-141
+    const int ld = ok ? cell(pi, pj, pk - pi + SR, pl - pj + SR, ss) : 0;
     // pyx:554-565: cases reproducing the cell; look-ahead adds the offset AND the source state
     const int r0 = ra >= 1, r1 = ra != 1, r2 = rb >= 1, r3 = rb != 1;
     const int t0 = d0 + (o0 - o2) + (r0 - r2), t1 = d1 + (o1 - o3) + (r1 - r3);
@@ -185,8 +190,10 @@ __global__ void __launch_bounds__(64) traceback_affine_kernel(const DeviceBatch 
 // Non-affine traceback (pyx:513-531): the first case, in generator order, that is
 // guard-valid and reproduces the cell; stops when none does (the origin).  One wave
 // per pair, lane c < 13 = case c; "first" = wave-min over the matching lane ids.
-template <int S, bool DO_TRACE, bool STRIP = false>  // STRIP: see traceback_affine_kernel
+template <int S, bool DO_TRACE, bool STRIP = false, bool WIDE = false>  // STRIP, WIDE: see traceback_affine_kernel
 __global__ void __launch_bounds__(64) traceback_linear_kernel(const DeviceBatch A, int npairs) {
+  static_assert(!WIDE || !STRIP, "no lean traceback on the wide-band path");
+  const int SR = WIDE ? A.wide_s : S;
   const int pid = A.order[blockIdx.x];
   const PairDesc pd = A.pairs[pid];
   const int n = pd.n, m = pd.m;
@@ -205,13 +212,14 @@ __global__ void __launch_bounds__(64) traceback_linear_kernel(const DeviceBatch 
   const int Qlo = STRIP ? max(Q - A.resw_k + 1, 0) : 0;
   const int64_t sstride = (int64_t)(m + Geo<S>::MAXOFF + 1) * Rec<S, 1>::RECDW;
   auto cell = [&](int pi, int pj, int a, int b) -> int {
+    if (WIDE) return lay[pd.layer_off + wide_dword(m, 2 * SR + 1, 1, pi, pj, a, b, 0)];
     if (!STRIP) return lay[cell_dword<S, 1>(pd, pi, pj, a, b, 0)];
     const int sp = pi / RR, ilp = pi - sp * RR + 1;
     if (sp >= Qlo)
       return A.scratch[pd.scratch_off + (Q - sp) * sstride + Rec<S, 1>::dword(pj + 2 * ilp + a, (ilp - 1) * W + a, b)];
     return lay[pd.layer_off + Rec<S, 1, true>::dword((int64_t)sp * pd.P + pj + 2 * ilp + a, a, b)];
   };
-  int cur = (STRIP && ts.started) ? ts.cur : cell(n, m, S, S);
+  int cur = (STRIP && ts.started) ? ts.cur : cell(n, m, SR, SR);
   if (c == 0 && !(STRIP && ts.started)) A.scores[pid] = cur;  // pyx:471
   if (!DO_TRACE) return;
   const TraceInputs in = stage_trace_inputs(A, pd, smem);
@@ -242,8 +250,8 @@ __global__ void __launch_bounds__(64) traceback_linear_kernel(const DeviceBatch 
                         : 0;
     const int sc = kconst + (use1 ? mu1 : 0) + (use2 ? mu2 : 0);
     const int pi = i - o0, pj = j - o1, pk = k - o2, pl = l - o3;
-    const bool ok = c < 13 && pi >= 0 && pj >= 0 && pk >= 0 && pl >= 0 && abs(pk - pi) <= S && abs(pl - pj) <= S;
-    const int ld = ok ? cell(pi, pj, pk - pi + S, pl - pj + S) : 0;
+    const bool ok = c < 13 && pi >= 0 && pj >= 0 && pk >= 0 && pl >= 0 && abs(pk - pi) <= SR && abs(pl - pj) <= SR;
+    const int ld = ok ? cell(pi, pj, pk - pi + SR, pl - pj + SR) : 0;
     const int key = (ok && ld + sc == cur) ? c : BIG;
     const int pick = __builtin_amdgcn_readfirstlane(wave_min16(key));
     if (pick == BIG) break;

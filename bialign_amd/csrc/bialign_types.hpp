@@ -49,6 +49,7 @@ struct DeviceBatch {
   int32_t* scratch;     // lean traceback: full records of resw_k strips per pair
   TraceState* tstate;   // lean traceback: [npairs]
   int32_t resw_k;       // lean traceback: strips re-swept (in parallel) and walked per round
+  int32_t wide_s;       // wide-band path (max_shift beyond the tiled kernels): the band half-width
   int32_t spin_limit;   // team hand-off: polls of the partner's progress word before a wave gives up (error flag)
 };
 

@@ -1,0 +1,208 @@
+// bialign_wide.hpp -- the recurrences for ANY max_shift (runtime band width).  Part of bialign_kernels.hpp.
+//
+// The tiled sweep (bialign_fill_affine.hpp / bialign_fill_linear.hpp) keeps a whole band row of
+// a lattice point in one lane's registers, which ends at max_shift 5 (~470 registers).  The
+// reference accepts any band width (pyx:25-35, bialign.py:83), so wider bands take this path:
+// a plain anti-diagonal wavefront.  Every predecessor of pyx:225-296 lowers the coordinate sum
+//   D = i + j + k + l
+// by at least one, so all lattice points of one D are independent: one workgroup per pair walks
+// D = 0 .. 2(n+m); within a level thread t takes (i, a, b) triples (j follows from D; only
+// every other b has the right parity).  Layers live in HBM in the reference's own order
+// [i][j][a][b][state] (pyx:38, state fastest), read back through L2 after a workgroup barrier
+// with agent-scope fences.  Straightforward and slow next to the tiled sweep -- one CU per
+// pair, every predecessor re-read from L2 -- but exact for any band, and a band this wide is
+// ~170+ cells per (i,j): the reference needs hours for what this does in seconds.
+#pragma once
+
+namespace bialign {
+
+// dword index of state st of lattice point (i, j, aa, bb) in a wide-band pair's region
+__host__ __device__ inline int64_t wide_dword(int m, int W, int NL, int i, int j, int aa, int bb, int st) {
+  return ((((int64_t)i * (m + 1) + j) * W + aa) * W + bb) * NL + st;
+}
+__host__ __device__ inline int64_t wide_pair_dwords(int n, int m, int S, int NL) {
+  const int64_t W = 2 * S + 1;
+  return (int64_t)(n + 1) * (m + 1) * W * W * NL;
+}
+
+struct WideCtx {
+  int n, m, S, W;
+  int beta, gamma, delta;
+  const int32_t *s1, *s2;
+  int k1, k2;
+  const uint8_t *sa, *ca, *sb, *cb;  // this pair's codes (global memory)
+  const int32_t* mu2tab;             // dense mu2 table of this pair or nullptr
+  int32_t* lay;                      // this pair's layers
+  __device__ __forceinline__ int mu1(int i, int j) const {  // pyx:435-436 (never contributes at i=0 or j=0)
+    return (i >= 1 && j >= 1) ? s1[sa[i - 1] * k1 + sb[j - 1]] : 0;
+  }
+  __device__ __forceinline__ int mu2(int k, int l) const {  // pyx:438-440
+    if (k < 1 || l < 1) return 0;
+    return mu2tab ? mu2tab[(int64_t)(k - 1) * m + (l - 1)] : s2[ca[k - 1] * k2 + cb[l - 1]];
+  }
+  __device__ __forceinline__ bool valid(int pi, int pj, int pk, int pl) const {  // pyx:133-141
+    return pi >= 0 && pj >= 0 && pk >= 0 && pl >= 0 && abs(pk - pi) <= S && abs(pl - pj) <= S;
+  }
+};
+
+// Visit every lattice point of level D with the threads of this workgroup.
+template <typename F>
+__device__ __forceinline__ void wide_for_level(const WideCtx& c, int D, F&& f) {
+  const int S = c.S, W = c.W, HW = (W + 1) / 2;
+  // j = (D - 2i - (aa-S) - (bb-S)) / 2 must lie in [0, m]
+  const int ilo = max(0, (D - 2 * c.m - 2 * S + 1) >> 1), ihi = min(c.n, (D + 2 * S) >> 1);
+  const int items = (ihi - ilo + 1) * W * HW;
+  for (int t = threadIdx.x; t < items; t += blockDim.x) {
+    const int hb = t % HW, aa = (t / HW) % W, i = ilo + t / (HW * W);
+    const int bb = 2 * hb + ((D - aa) & 1);  // aa + bb must have D's parity
+    if (bb >= W) continue;
+    const int rem = D - 2 * i - (aa - S) - (bb - S);
+    if (rem < 0 || rem > 2 * c.m) continue;
+    const int j = rem >> 1, k = i + aa - S, l = j + bb - S;
+    if (k < 0 || k > c.n || l < 0 || l > c.m) continue;
+    f(i, j, k, l, aa, bb);
+  }
+}
+
+// Layers written at one level are read at the next ones by other waves of the workgroup:
+// write back / invalidate around the barrier (all waves share this CU's L2).
+__device__ __forceinline__ void wide_level_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
+
+// ---------------------------------------------------------------------------
+// Affine fill (pyx:474-509), literal: per target state the fifteen cases of pyx:275-296.
+// ---------------------------------------------------------------------------
+template <int UNUSED = 0>  // (a template so that only bialign_wide.hip instantiates it)
+__global__ void __launch_bounds__(1024) fill_wide_affine_kernel(const DeviceBatch A, int S) {
+  const int pid = A.order[blockIdx.x];
+  const PairDesc pd = A.pairs[pid];
+  WideCtx c;
+  c.n = pd.n; c.m = pd.m; c.S = S; c.W = 2 * S + 1;
+  c.beta = A.beta; c.gamma = A.gamma; c.delta = A.delta;
+  c.s1 = A.s1; c.s2 = A.s2; c.k1 = A.k1; c.k2 = A.k2;
+  c.sa = A.seq_a + pd.seq_a; c.ca = A.cls_a + pd.seq_a; c.sb = A.seq_b + pd.seq_b; c.cb = A.cls_b + pd.seq_b;
+  c.mu2tab = A.mu2_dense ? A.mu2_dense + pd.mu2_off : nullptr;
+  c.lay = A.layers + pd.layer_off;
+  const int n = c.n, m = c.m, W = c.W;
+  const int beta = c.beta, gamma = c.gamma, delta = c.delta;
+
+  for (int D = 0; D <= 2 * (n + m); ++D) {
+    wide_for_level(c, D, [&](int i, int j, int k, int l, int aa, int bb) {
+      int32_t* out = c.lay + wide_dword(m, W, 9, i, j, aa, bb, 0);
+      if (D == 0) {  // pyx:483-485
+#pragma unroll
+        for (int q = 0; q < 9; ++q) out[q] = q == 8 ? 0 : NEG;
+        return;
+      }
+      const int mu1 = c.mu1(i, j), mu2 = c.mu2(k, l);
+#pragma unroll
+      for (int hU = 0; hU < 3; ++hU) {
+#pragma unroll
+        for (int hV = 0; hV < 3; ++hV) {
+          const int u0 = hU >= 1, u1 = hU != 1, v0 = hV >= 1, v1 = hV != 1;
+          const int valU = hU == 2 ? mu1 : gamma, valV = hV == 2 ? mu2 : gamma;
+          bool any = false;
+          int best = NEG;  // pyx:299-303: no valid case -> exactly NEG
+          auto take = [&](int v) { best = any ? (v > best ? v : best) : v; any = true; };
+          {  // group 1 (pyx:275-279): offset = the target state, all nine sources
+            const int pi = i - u0, pj = j - u1, pk = k - v0, pl = l - v1;
+            if (c.valid(pi, pj, pk, pl)) {
+              const int32_t* src = c.lay + wide_dword(m, W, 9, pi, pj, pk - pi + S, pl - pj + S, 0);
+              const int sh = hU == hV ? 0 : ((hU == 2 || hV == 2) ? 1 : 2);
+              const int base = delta * sh + valU + valV;
+#pragma unroll
+              for (int r = 0; r < 9; ++r) {
+                const int ra = r / 3, rb = r % 3;
+                take(src[r] + base + ((hU != 2 && ra != hU) ? beta : 0) + ((hV != 2 && rb != hV) ? beta : 0));
+              }
+            }
+          }
+          {  // group 2 (pyx:284-290): offset (0,0,V), sources (U,h), h = M, X, Y
+            const int pk = k - v0, pl = l - v1;
+            if (c.valid(i, j, pk, pl)) {
+              const int32_t* src = c.lay + wide_dword(m, W, 9, i, j, pk - i + S, pl - j + S, 0);
+              const int base = delta * (v0 + v1) + valV;
+#pragma unroll
+              for (int h = 2; h >= 0; --h) take(src[3 * hU + h] + base + ((hV != 2 && h != hV) ? beta : 0));
+            }
+          }
+          {  // group 3 (pyx:291-296): offset (U,0,0), sources (h,V)
+            const int pi = i - u0, pj = j - u1;
+            if (c.valid(pi, pj, k, l)) {
+              const int32_t* src = c.lay + wide_dword(m, W, 9, pi, pj, k - pi + S, l - pj + S, 0);
+              const int base = delta * (u0 + u1) + valU;
+#pragma unroll
+              for (int h = 2; h >= 0; --h) take(src[3 * h + hV] + base + ((hU != 2 && h != hU) ? beta : 0));
+            }
+          }
+          out[3 * hU + hV] = best;
+        }
+      }
+    });
+    wide_level_sync();
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Non-affine fill (pyx:443-471): thirteen cases (pyx:233-248), one layer.
+// ---------------------------------------------------------------------------
+template <int UNUSED = 0>
+__global__ void __launch_bounds__(1024) fill_wide_linear_kernel(const DeviceBatch A, int S) {
+  const int pid = A.order[blockIdx.x];
+  const PairDesc pd = A.pairs[pid];
+  WideCtx c;
+  c.n = pd.n; c.m = pd.m; c.S = S; c.W = 2 * S + 1;
+  c.beta = A.beta; c.gamma = A.gamma; c.delta = A.delta;
+  c.s1 = A.s1; c.s2 = A.s2; c.k1 = A.k1; c.k2 = A.k2;
+  c.sa = A.seq_a + pd.seq_a; c.ca = A.cls_a + pd.seq_a; c.sb = A.seq_b + pd.seq_b; c.cb = A.cls_b + pd.seq_b;
+  c.mu2tab = A.mu2_dense ? A.mu2_dense + pd.mu2_off : nullptr;
+  c.lay = A.layers + pd.layer_off;
+  const int n = c.n, m = c.m, W = c.W;
+  const int gamma = c.gamma, delta = c.delta, gD = gamma + delta;
+  constexpr int OFF[13] = {15, 10, 5, 12, 3, 8, 4, 2, 1, 11, 7, 14, 13};  // o0*8+o1*4+o2*2+o3, generator order
+
+  for (int D = 0; D <= 2 * (n + m); ++D) {
+    wide_for_level(c, D, [&](int i, int j, int k, int l, int aa, int bb) {
+      int32_t* out = c.lay + wide_dword(m, W, 1, i, j, aa, bb, 0);
+      if (D == 0) { *out = 0; return; }  // zero-initialised storage (pyx:452)
+      const int mu1 = c.mu1(i, j), mu2 = c.mu2(k, l);
+      bool any = false;
+      int best = NEG;
+#pragma unroll
+      for (int t = 0; t < 13; ++t) {
+        const int o0 = (OFF[t] >> 3) & 1, o1 = (OFF[t] >> 2) & 1, o2 = (OFF[t] >> 1) & 1, o3 = OFF[t] & 1;
+        const int pi = i - o0, pj = j - o1, pk = k - o2, pl = l - o3;
+        if (!c.valid(pi, pj, pk, pl)) continue;
+        const int use1 = (t == 0 || t == 3 || t == 11 || t == 12), use2 = (t == 0 || t == 4 || t == 9 || t == 10);
+        const int kconst = t == 0 ? 0 : (t <= 2 ? 2 * gamma : (t <= 4 ? delta : gD));
+        const int v = c.lay[wide_dword(m, W, 1, pi, pj, pk - pi + S, pl - pj + S, 0)] + kconst + (use1 ? mu1 : 0) +
+                      (use2 ? mu2 : 0);
+        best = any ? (v > best ? v : best) : v;
+        any = true;
+      }
+      *out = best;
+    });
+    wide_level_sync();
+  }
+}
+
+// Layers in the reference layout for the test hook (same order already; out-of-lattice band slots -> 0).
+template <int NL>
+__global__ void dump_wide_kernel(const DeviceBatch A, int S, int pid, int32_t* out) {
+  const int W = 2 * S + 1;
+  const PairDesc pd = A.pairs[pid];
+  const int n = pd.n, m = pd.m;
+  const int64_t cells = (int64_t)(n + 1) * (m + 1) * W * W;
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < cells; t += (int64_t)gridDim.x * blockDim.x) {
+    const int bb = t % W, aa = (t / W) % W;
+    const int j = (t / (W * W)) % (m + 1), i = t / ((int64_t)W * W * (m + 1));
+    const int k = i + aa - S, l = j + bb - S;
+    const bool ok = k >= 0 && k <= n && l >= 0 && l <= m;
+    for (int q = 0; q < NL; ++q) out[q * cells + t] = ok ? A.layers[pd.layer_off + t * NL + q] : 0;
+  }
+}
+
+}  // namespace bialign

@@ -35,12 +35,20 @@ extern "C" {
 
 #define BIALIGN_OK 0
 #define BIALIGN_E_INVALID (-1)     /* bad argument (message says which) */
-#define BIALIGN_E_UNSUPPORTED (-2) /* e.g. max_shift above BIALIGN_MAX_SHIFT */
+#define BIALIGN_E_UNSUPPORTED (-2) /* e.g. reduced storage at max_shift above BIALIGN_MAX_SHIFT_TILED */
 #define BIALIGN_E_DEVICE (-3)      /* HIP runtime error */
 #define BIALIGN_E_NOMEM (-4)       /* a single pair does not fit the HBM budget */
 #define BIALIGN_E_RANGE (-5)       /* scores could leave the int32 safety window */
 
-#define BIALIGN_MAX_SHIFT 5 /* kernels are instantiated for max_shift 0..5 */
+/* max_shift: any band width the reference takes (pyx:25-35; bialign.py:83 has no upper bound).  Bands up to
+ * BIALIGN_MAX_SHIFT_TILED run the tiled register/LDS sweep (the fast path, all storage modes); wider bands
+ * run a plain anti-diagonal kernel over layers kept in the reference's own array order (one workgroup per
+ * pair, full storage only).  BIALIGN_MAX_SHIFT merely bounds the index arithmetic. */
+#define BIALIGN_MAX_SHIFT_TILED 5
+#define BIALIGN_MAX_SHIFT 1024
+/* Molecule length: the tiled sweep stages both molecules' codes (2 bytes per residue and molecule) next to
+ * its exchange arrays in one workgroup's LDS, the tracebacks stage them next to the score tables: the sum
+ * must fit 160 KiB, i.e. n + m below ~60 000 residues at small alphabets (BIALIGN_E_UNSUPPORTED beyond). */
 #define BIALIGN_NEG_INF (-(1 << 30)) /* the reference's -infinity, pyx:303,484 */
 
 /* bialign_params.recurrence */
@@ -71,7 +79,7 @@ typedef struct bialign_params {
   int32_t gap_opening_cost; /* beta; != 0 selects the affine recurrence (pyx:204-205, 444) */
   int32_t gap_cost;         /* gamma */
   int32_t shift_cost;       /* Delta */
-  int32_t max_shift;        /* s, 0..BIALIGN_MAX_SHIFT */
+  int32_t max_shift;        /* s >= 0 (see BIALIGN_MAX_SHIFT_TILED) */
   int32_t recurrence;       /* BIALIGN_REC_AUTO: affine iff gap_opening_cost != 0, as optimize()
                                dispatches (pyx:444); BIALIGN_REC_AFFINE = affine_optimize() called
                                directly (pyx:474); BIALIGN_REC_LINEAR = the 13-case recurrence */

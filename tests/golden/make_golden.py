@@ -122,11 +122,38 @@ def run_cli(args):
     return out.stdout
 
 
+def wide_band(ba):
+    """max_shift beyond the tiled kernels (6, 7, 8, 10): full layer dumps on small inputs (also
+    bands wider than the molecules), traces on medium ones, both recurrences, RNA and protein."""
+    pp = synth.PROTEIN_PARAMS
+    lin = dict(gap_opening_cost=0, gap_cost=-200, shift_cost=-250)
+    out = []
+    for seed, n, m, ov, layers in [
+            (61, 9, 8, dict(max_shift=6), True), (62, 10, 12, dict(max_shift=8), True),
+            (63, 3, 5, dict(max_shift=7), True), (64, 14, 6, dict(max_shift=6, gap_opening_cost=80), True),
+            (65, 8, 9, dict(max_shift=6, **lin), True), (66, 12, 10, dict(max_shift=10, **lin), True),
+            (67, 1, 1, dict(max_shift=8), True), (68, 26, 30, dict(max_shift=6), False),
+            (69, 24, 20, dict(max_shift=8, shift_cost=-20), False), (70, 30, 28, dict(max_shift=7, **lin), False)]:
+        sa, sb, ta, tb = synth.protein_pair(seed, n, m)
+        out.append(run_case(ba, f"protein_s{seed}_{n}x{m}", sa, sb, ta, tb, dict(pp, **ov), layers=layers,
+                            decode=False))
+    for seed, n, m, ov, layers in [(71, 10, 9, dict(max_shift=6), True), (72, 22, 24, dict(max_shift=8), False)]:
+        sa, sb, ta, tb = synth.rna_pair(seed, n, m)
+        out.append(run_case(ba, f"rna_s{seed}_{n}x{m}", sa, sb, ta, tb, dict(synth.RNA_PARAMS, **ov),
+                            layers=layers, decode=True, modes=("default", "sorted")))
+    with open(os.path.join(HERE, "wide_band.json"), "w") as fh:
+        json.dump(out, fh, separators=(",", ":"))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--dnapol", action="store_true")
+    ap.add_argument("--only-wide", action="store_true", help="only wide_band.json (max_shift 6..10)")
     opts = ap.parse_args()
     ba = build_reference()
+    wide_band(ba)
+    if opts.only_wide:
+        return
 
     RNA_A, RNA_B = "GCGGGGGAUAUCCCCAUCG", "GGGGAUAUCCCCAUCG"
     RNA_SA, RNA_SB = "...(((.....))).....", ".(((.....)))...."

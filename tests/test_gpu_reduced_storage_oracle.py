@@ -33,9 +33,10 @@ def one_case(case, mode, k, monkeypatch):
     monkeypatch.setenv("BIALIGN_RESW_K", str(k))
     kw = dict(score_only=(mode == "score_only"), lean_trace=(mode == "lean_trace"))
     if mode == "auto_lean":   # a budget below one pair's full layers: the engine must switch to lean traceback itself
-        w = 2 * s + 1
-        biggest = max((n + 1) * (m + 1) * w * w * (36 if affine else 4) for n, m in shapes)
-        kw["hbm_budget_bytes"] = max(biggest // 3, 1 << 20)
+        big = max(range(len(shapes)), key=lambda t: shapes[t][0] * shapes[t][1])
+        probe = make_batch([pairs[big]], params, mu2_dense=[tabs[big]] if dense else None)
+        kw["hbm_budget_bytes"] = int(probe.info["hbm_layer_bytes"] * 0.6)
+        probe.close()
     b = make_batch(pairs, params, mu2_dense=tabs, **kw)
     if mode == "auto_lean":
         assert b.info["storage"] == 2  # BIALIGN_BATCH_LEAN_TRACE, chosen by the engine

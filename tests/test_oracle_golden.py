@@ -10,6 +10,7 @@ from oracle import oracle
 KNOWN = load_golden("known_answers.json")
 SMALL = load_golden("small_layers.json")
 MEDIUM = load_golden("medium_traces.json")
+WIDE = load_golden("wide_band.json")  # max_shift 6..10 (the anti-diagonal path of the engine)
 
 
 def check(rec):
@@ -44,6 +45,11 @@ def test_small_full_layers(rec):
 
 @pytest.mark.parametrize("rec", MEDIUM, ids=[r["name"] for r in MEDIUM])
 def test_medium_traces(rec):
+    check(rec)
+
+
+@pytest.mark.parametrize("rec", WIDE, ids=[r["name"] for r in WIDE])
+def test_wide_band_cases(rec):
     check(rec)
 
 
