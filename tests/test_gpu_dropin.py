@@ -197,9 +197,12 @@ def test_c_abi_error_paths():
     from bialign_amd.batch import make_batch
     from bialign_amd.engine import Engine
     pairs = [synth.protein_pair(1, 12, 9)]
-    with pytest.raises(_lib.BialignError) as e:
-        make_batch(pairs, dict(synth.PROTEIN_PARAMS, max_shift=6))
+    with pytest.raises(_lib.BialignError) as e:   # wide bands run (test_gpu_wide_band.py), but not in reduced storage
+        make_batch(pairs, dict(synth.PROTEIN_PARAMS, max_shift=6), score_only=True)
     assert e.value.code == _lib.E_UNSUPPORTED and "max_shift" in e.value.message
+    with pytest.raises(_lib.BialignError) as e:
+        make_batch(pairs, dict(synth.PROTEIN_PARAMS, max_shift=-1))
+    assert e.value.code == _lib.E_INVALID
     with pytest.raises(_lib.BialignError) as e:
         make_batch(pairs, dict(synth.PROTEIN_PARAMS, structure_weight=1 << 27))
     assert e.value.code == _lib.E_RANGE
