@@ -33,7 +33,7 @@ int fail(int code, const char* fmt, ...) {
 //    long pairs).  Every workgroup of the launch must be resident at once (a wave spins on its
 //    predecessor), so the grid is capped by the residency the runtime's occupancy calculation gives
 //    for the actual kernel (xcu_resident; 0 = cross-CU teams not available for this launch).
-TeamShape team_shape(const bialign_batch* b, int first, int count, int xcu_resident) {
+TeamShape team_shape(const bialign_batch* b, int first, int count, int xcu_resident, int xcu8_resident) {
   TeamShape ts;
   const int W = 2 * b->S + 1, R = 64 / W;
   const int lag = 2 * (R - 1) + 2 * ghost_blk(b->S) + 16;
@@ -45,17 +45,31 @@ TeamShape team_shape(const bialign_batch* b, int first, int count, int xcu_resid
   }
   int fit = 1;  // in-workgroup teams come in powers of two (kernel template parameter)
   while (fit * 2 <= fit_exact) fit *= 2;
-  // the one-layer (non-affine) kernel is small in registers at every s
-  int tw = std::min(fit, !b->affine ? 8 : (b->S <= 1 ? 8 : (b->S <= 3 ? 4 : 1)));
-  while (tw > 1 && b->lds_base + (size_t)tw * b->lds_per_wave > 160 * 1024) tw >>= 1;
+  // LDS of a workgroup of t waves (the eight-wave s=2 affine kernel has its own, leaner layout)
+  const bool diet8 = diet8_available(b);
+  auto lds_of = [&](int t) { return (t == 8 && diet8) ? b->lds_diet8 : b->lds_base + (size_t)t * b->lds_per_wave; };
+  // the one-layer (non-affine) kernel is small in registers at every s; the affine one fits two waves per
+  // SIMD up to s=2 (s=2: eight waves only in the diet layout), one at s=3, and needs the whole SIMD beyond
+  int tw = std::min(fit, !b->affine ? 8 : (b->S <= 1 ? 8 : (b->S == 2 ? (diet8 ? 8 : 4) : (b->S == 3 ? 4 : 1))));
+  while (tw > 1 && lds_of(tw) > 160 * 1024) tw >>= 1;
   if (b->dense) tw = std::min(tw, 2);  // dense-mu2 kernels are instantiated for 1 and 2 waves
   // cross-CU teams (affine LOOKUP kernels only) take any size: the team is a runtime value there
   int gw = (b->affine && b->S <= 3 && !b->dense && xcu_resident > 0) ? fit_exact : 1;
   gw = std::max(1, std::min(gw, xcu_resident / std::max(count, 1)));
+  // ... and, for the s=2 sweep, teams of eight-wave workgroups (one per CU, two waves per SIMD)
+  int gw8 = (diet8 && xcu8_resident > 0) ? std::min(fit_exact / 8, xcu8_resident / std::max(count, 1)) : 0;
 
-  const char* e = getenv("BIALIGN_TEAM");  // experiments / tests: "N" in-workgroup, "xN" cross-CU
+  const char* e = getenv("BIALIGN_TEAM");  // experiments / tests: "N" in-workgroup, "xN" cross-CU, "hN" N eight-wave workgroups
+  if (e && !*e) e = nullptr;
   if (e && e[0] == 'x') {
     ts.gw = std::max(1, std::min(atoi(e + 1), gw));
+    return ts;
+  }
+  if (e && e[0] == 'h') {
+    if (gw8 >= 1 && tw == 8) {
+      ts.tw = 8;
+      ts.gw = std::max(1, std::min(atoi(e + 1), gw8));
+    }
     return ts;
   }
   if (e) {
@@ -68,7 +82,7 @@ TeamShape team_shape(const bialign_batch* b, int first, int count, int xcu_resid
   // how many workgroups of that size a CU holds (LDS, registers)
   const int waves_cu_regs = !b->affine ? 16 : (b->S <= 1 ? 12 : (b->S == 2 ? 8 : 4));
   auto concurrent = [&](int t) {
-    const size_t lds = (b->lds_base + (size_t)t * b->lds_per_wave + 1023) / 1024 * 1024;
+    const size_t lds = (lds_of(t) + 1023) / 1024 * 1024;
     const int wg_cu = (int)std::min<size_t>((160 * 1024) / lds, (size_t)(waves_cu_regs / t));
     return std::min<int64_t>((int64_t)count * t, (int64_t)b->eng->num_cu * wg_cu * t);
   };
@@ -85,9 +99,20 @@ TeamShape team_shape(const bialign_batch* b, int first, int count, int xcu_resid
   // cross-CU: when the chip would stay mostly empty and the team can be at least doubled -- or, for
   // a handful of pairs, not doubled but spread: eight waves on eight CUs beat eight waves sharing
   // one CU's SIMDs two by two (one 928 x 933 pair: 7.6 vs 9.4 ms)
+  int64_t running = concurrent(t);
   if (count * t <= 512) {
     const int g = std::min(gw, std::max(1, 2048 / count));
-    if (g >= 2 * t || (t == 8 && g >= 8 && count * 8 <= b->eng->num_cu)) { ts.tw = 1; ts.gw = g; }
+    if (g >= 2 * t || (t == 8 && g >= 8 && count * 8 <= b->eng->num_cu)) {
+      ts.tw = 1;
+      ts.gw = g;
+      running = (int64_t)count * g;
+    }
+  }
+  // s=2: eight-wave workgroups spread over CUs when that keeps more waves running than either of the above
+  // (64 pairs x len 2000: 4 workgroups per pair = 2048 waves, two per SIMD, against 1024 one-wave workgroups)
+  if (gw8 >= 2 && (int64_t)count * gw8 * 8 * 100 >= running * 125) {
+    ts.tw = 8;
+    ts.gw = gw8;
   }
   return ts;
 }
@@ -141,11 +166,13 @@ int64_t cells_of(int n, int m, int s) {
   return K(n) * K(m);
 }
 
-size_t lds_need(int S, int NL, int team, int k1, int k2, int n, int m, bool dense = false) {
+// diet: the eight-wave form of the s=2 affine kernel (fill_affine_kernel, DIET): half-length ghost blocks,
+// molecule A's codes not staged
+size_t lds_need(int S, int NL, int team, int k1, int k2, int n, int m, bool dense = false, bool diet = false) {
   const int W = 2 * S + 1, PADB = S + 1;
   const size_t nv = (NL == 9 ? 12 : 1) * W;
-  const size_t npad = (n + 3) & ~3, mpad = (m + 2 * PADB + 3) & ~3;
-  const int nd = NL * W, np = nd / 4 + (nd % 4 ? 1 : 0), blk = ghost_blk(S);
+  const size_t npad = diet ? 0 : (n + 3) & ~3, mpad = (m + 2 * PADB + 3) & ~3;
+  const int nd = NL * W, np = nd / 4 + (nd % 4 ? 1 : 0), blk = diet ? 2 : ghost_blk(S);
   const size_t ring_dw = 2 * (((size_t)blk * W * np + 63) / 64 * 64) * 4;  // GhostFeed<S,NL>::RING_DW
   const size_t shared_dw = 16 + (size_t)k1 * k1 + (size_t)k2 * k2;  // progress words + score tables
   const size_t mu2_ring_dw = dense ? 2 * (size_t)blk * 64 : 0;  // Mu2Feed<S>::RING_DW
@@ -391,6 +418,7 @@ int bialign_batch_create(bialign_engine* eng, const bialign_params* prm, const b
     if (!b->wide) {
       b->lds_bytes = std::max(b->lds_bytes, lds_need(S, b->NL, 1, sc->k1, sc->k2, n, m, b->dense));
       b->lds_base = std::max(b->lds_base, lds_need(S, b->NL, 0, sc->k1, sc->k2, n, m, b->dense));
+      b->lds_diet8 = std::max(b->lds_diet8, lds_need(S, b->NL, 8, sc->k1, sc->k2, n, m, false, true));
     }
     b->lds_trace = std::max<size_t>(b->lds_trace, ((size_t)sc->k1 * sc->k1 + (size_t)sc->k2 * sc->k2) * 4 +
                                                       2 * (size_t)((n + 3) & ~3) + 2 * (size_t)((m + 3) & ~3));

@@ -17,7 +17,9 @@ namespace bialign {
 // one counted wait per block is written by hand.  The ghost of step g replays
 // record g - GOFF for every ghost lane alike, so the feed needs no lane state.
 // ---------------------------------------------------------------------------
-template <int S, int NL, bool LEAN = false>
+//   BLKO: 0 = the default block length of this max_shift, else the block length (the diet
+//   variant of the s=2 kernel halves its ring to fit eight waves' arrays into one CU's LDS).
+template <int S, int NL, bool LEAN = false, int BLKO = 0>
 struct GhostFeed {
   using R_ = Rec<S, NL, LEAN>;
   static constexpr int W = 2 * S + 1, R = 64 / W;
@@ -25,7 +27,7 @@ struct GhostFeed {
 #ifdef BIALIGN_BLK_OVERRIDE
   static constexpr int BLK = BIALIGN_BLK_OVERRIDE;
 #else
-  static constexpr int BLK = S <= 1 ? 8 : 4;  // steps per prefetch block (the ring is 2*BLK*W*NP*16 bytes of LDS)
+  static constexpr int BLK = BLKO ? BLKO : (S <= 1 ? 8 : 4);  // steps per prefetch block (the ring is 2*BLK*W*NP*16 bytes of LDS)
 #endif
   static constexpr int NPIECE = BLK * W * NP;
   static constexpr int ROUNDS = (NPIECE + 63) / 64;
@@ -77,6 +79,8 @@ struct GhostFeed {
   __device__ static __forceinline__ void wait_block(int younger) {
     if (younger > 40) asm volatile("s_waitcnt vmcnt(40)" ::: "memory");
     else if (younger > 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+    else if (younger > 20) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+    else if (younger > 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
     else if (younger > 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
     else if (younger > 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     else if (younger > 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");

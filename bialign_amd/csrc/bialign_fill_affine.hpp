@@ -49,8 +49,8 @@ struct BoolTag {
 // steps, and wave 0 may lead wave T-1 by at most P-lag: the host picks T only if
 // T*lag fits into P with room to spare (team_shape()).
 //   XCU = false: the team is one workgroup of TW waves (T = TW), progress words in LDS.
-//   XCU = true : the team is A.team one-wave workgroups on any CUs / XCDs (T = A.team,
-//     block b -> pair b / T, wave b % T; all co-resident by construction of the grid).
+//   XCU = true : the team is A.team workgroups of TW waves on any CUs / XCDs (T = A.team * TW,
+//     block b -> pair b / A.team, waves (b % A.team) * TW ..; all co-resident by construction of the grid).
 //     Per-XCD L2s are not coherent, so every layer store is write-through (sc1), the ghost
 //     DMAs and the progress words are sc1 accesses too, and a word is published only
 //     after the stores it covers have left the wave's vector-memory queue.
@@ -71,7 +71,12 @@ __device__ __forceinline__ void store_chunk(int32_t* p, v4i v) {
 //   strip the walk stands in is swept only up to the walk's column.  One wave per strip.
 template <int S, bool BETA_NONPOS, int TW, bool XCU, bool DENSE = false, bool LEAN = false, bool RESW = false>
 __global__ void __launch_bounds__(64 * TW) fill_affine_kernel(const DeviceBatch A) {
-  static_assert(!XCU || TW == 1, "cross-CU teams are built from one-wave workgroups");
+  static_assert(!XCU || TW == 1 || TW == 8, "cross-CU teams are built from one-wave or eight-wave workgroups");
+  // DIET (eight waves of the s=2 kernel in one workgroup = two per SIMD on a whole CU): their arrays fit
+  // 160 KB of LDS only with half-length ghost blocks and molecule A's codes left in global memory (they
+  // are read once per strip, in set_row).
+  constexpr bool DIET = TW == 8 && S == 2;
+  static_assert(!DIET || (!DENSE && !RESW), "the diet variant exists for LOOKUP sweeps only");
   static_assert(!RESW || (TW == 1 && !XCU && !LEAN), "strip re-sweeps: one wave, full records");
   using G_ = Geo<S>;
   using R_ = Rec<S, 9, LEAN>;
@@ -80,8 +85,8 @@ __global__ void __launch_bounds__(64 * TW) fill_affine_kernel(const DeviceBatch 
   constexpr int NV = XR * W, ND = R_::ND, NCH4 = R_::NCH4, TAIL = R_::TAIL, RECDW = R_::RECDW;
   extern __shared__ __align__(16) int32_t smem[];
 
-  const int T = XCU ? A.team : TW;                       // team size
-  const int slot = XCU ? blockIdx.x / T : (RESW ? blockIdx.x / A.resw_k : blockIdx.x);  // pair of this launch
+  const int T = XCU ? A.team * TW : TW;                  // team size
+  const int slot = XCU ? blockIdx.x / A.team : (RESW ? blockIdx.x / A.resw_k : blockIdx.x);  // pair of this launch
   const int pid = A.order[slot];
   const PairDesc pd = A.pairs[pid];
   const int n = pd.n, m = pd.m, P = pd.P;
@@ -96,7 +101,7 @@ __global__ void __launch_bounds__(64 * TW) fill_affine_kernel(const DeviceBatch 
   }
   const int L = threadIdx.x & 63;
   const int wl = TW == 1 ? 0 : __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave in workgroup
-  const int w = XCU ? (int)(blockIdx.x - slot * T) : wl;                              // wave in team
+  const int w = XCU ? (int)(blockIdx.x - slot * A.team) * TW + wl : wl;               // wave in team
   const int il = L / W, aa = L - il * W;
   const bool live = L < R * W;
   const bool ghost = (il == 0);
@@ -106,7 +111,7 @@ __global__ void __launch_bounds__(64 * TW) fill_affine_kernel(const DeviceBatch 
 
   // ---- LDS carve-up: per wave a ghost ring and an exchange array; shared: progress
   //      words, score tables, sequence codes
-  using GF = GhostFeed<S, 9, LEAN || RESW>;  // a re-sweep replays LEAN records
+  using GF = GhostFeed<S, 9, LEAN || RESW, DIET ? 2 : 0>;  // a re-sweep replays LEAN records
   using MF = Mu2Feed<S>;
   constexpr int PERW = GF::RING_DW + NV * NCOL + (DENSE ? MF::RING_DW : 0);  // dwords per wave
   v4i* ring = reinterpret_cast<v4i*>(smem + wl * GF::RING_DW);   // ghost-row ring, two halves
@@ -116,19 +121,20 @@ __global__ void __launch_bounds__(64 * TW) fill_affine_kernel(const DeviceBatch 
   int32_t* s1 = smem + TW * PERW + 16;                            // [k1*k1]
   int32_t* s2 = s1 + k1 * k1;                                   // [k2*k2]
   const int npad = (n + 3) & ~3, mpad = (m + 2 * PADB + 3) & ~3;
-  uint8_t* sa = reinterpret_cast<uint8_t*>(s2 + k2 * k2);  // seq A codes, [i-1]
+  uint8_t* sa = reinterpret_cast<uint8_t*>(s2 + k2 * k2);  // seq A codes, [i-1]   (DIET: not staged)
   uint8_t* ca = sa + npad;                                  // cls A,       [k-1]
-  uint8_t* sb = ca + npad;                                  // seq B codes, [j-1+PADB]
+  uint8_t* sb = DIET ? sa : ca + npad;                      // seq B codes, [j-1+PADB]
   uint8_t* cb = sb + mpad;                                  // cls B,       [l-1+PADB]
 
   for (int t = threadIdx.x; t < TW * PERW; t += 64 * TW) smem[t] = SENT;
   if (threadIdx.x < 16) prog_lds[threadIdx.x] = 0;
   for (int t = threadIdx.x; t < k1 * k1; t += 64 * TW) s1[t] = A.s1[t];
   for (int t = threadIdx.x; t < k2 * k2; t += 64 * TW) s2[t] = A.s2[t];
-  for (int t = threadIdx.x; t < n; t += 64 * TW) {
-    sa[t] = A.seq_a[pd.seq_a + t];
-    ca[t] = A.cls_a[pd.seq_a + t];
-  }
+  if (!DIET)
+    for (int t = threadIdx.x; t < n; t += 64 * TW) {
+      sa[t] = A.seq_a[pd.seq_a + t];
+      ca[t] = A.cls_a[pd.seq_a + t];
+    }
   for (int t = threadIdx.x; t < m + 2 * PADB; t += 64 * TW) {
     const int src = t - PADB;
     const bool ok = src >= 0 && src < m;
@@ -161,8 +167,14 @@ __global__ void __launch_bounds__(64 * TW) fill_affine_kernel(const DeviceBatch 
     i = (Qbase + q * T + w) * RR + il - 1;
     const int k = i + aa - S;
     act_row = live && i >= 0 && i <= n && k >= 0 && k <= n;
-    s1row = (i >= 1 && i <= n) ? sa[i - 1] * k1 : 0;
-    s2row = (k >= 1 && k <= n) ? ca[k - 1] * k2 : 0;
+    if (DIET) {  // once per strip: two byte loads from global memory, consumed right here
+      s1row = (i >= 1 && i <= n) ? A.seq_a[pd.seq_a + i - 1] * k1 : 0;
+      s2row = (k >= 1 && k <= n) ? A.cls_a[pd.seq_a + k - 1] * k2 : 0;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+      s1row = (i >= 1 && i <= n) ? sa[i - 1] * k1 : 0;
+      s2row = (k >= 1 && k <= n) ? ca[k - 1] * k2 : 0;
+    }
   };
   set_row(0);
 

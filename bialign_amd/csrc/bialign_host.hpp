@@ -100,6 +100,7 @@ struct bialign_batch {
   int64_t cells = 0, trace_bytes = 0, max_chunk_dwords = 0;
   size_t lds_bytes = 0;                   // dynamic LDS of a one-wave workgroup
   size_t lds_base = 0, lds_per_wave = 0;  // team launches: lds_base + T * lds_per_wave
+  size_t lds_diet8 = 0;                   // eight-wave workgroups of the s=2 affine kernel (DIET layout)
   size_t lds_trace = 0;                   // tracebacks: score tables + sequence codes
   DevBuf<PairDesc> d_pairs;
   DevBuf<int32_t> d_order, d_s1, d_s2, d_layers, d_scores, d_tlen, d_complete, d_err, d_prog;
@@ -108,7 +109,7 @@ struct bialign_batch {
   // occupancy the runtime reports for the actual kernel (xcu_resident, cached per LEAN flavour) and
   // launches of this kind are serialised across the engines of a process; if a hand-off still times
   // out (another tenant on the device), the run is repeated with in-workgroup teams (no_xcu).
-  int xcu_resident[2] = {-1, -1};
+  int xcu_resident[4] = {-1, -1, -1, -1};  // [LEAN + 2 * (eight-wave workgroups)]
   bool used_xcu = false;   // a fill launch of the pending / last run was a cross-CU team
   bool no_xcu = false;     // a cross-CU launch of this batch failed once: in-workgroup teams from now on
   int recovered = 0;       // runs repeated after a hand-off timeout
@@ -166,8 +167,12 @@ struct TeamShape {
   int waves() const { return tw * gw; }
 };
 
-// xcu_resident: one-wave workgroups of the cross-CU kernel the device holds at once (0: no such kernel)
-TeamShape team_shape(const bialign_batch* b, int first, int count, int xcu_resident);
+// xcu_resident: one-wave workgroups of the cross-CU kernel the device holds at once (0: no such kernel);
+// xcu8_resident: likewise its eight-wave workgroups (s=2 affine sweep only, else 0)
+TeamShape team_shape(const bialign_batch* b, int first, int count, int xcu_resident, int xcu8_resident = 0);
+inline bool diet8_available(const bialign_batch* b) {  // the eight-wave s=2 affine kernel and its LDS layout
+  return b->affine && b->S == 2 && !b->dense && b->lds_diet8 <= 160 * 1024;
+}
 // Cross-CU launches of all engines of this process on one device run one after the other (each needs
 // the whole device's wave slots): the stream waits for the previous such launch, the new one is recorded.
 int xcu_serial_begin(bialign_engine* e);
@@ -179,7 +184,7 @@ int launch_fill_affine_t(bialign_batch* b, const DeviceBatch& v, int first, int 
   w.order = v.order + first;
   w.team = gw;
   auto kern = fill_affine_kernel<S, BETA_NONPOS, TW, XCU, DENSE, LEAN>;
-  const size_t lds = b->lds_base + (size_t)TW * b->lds_per_wave;
+  const size_t lds = (S == 2 && TW == 8) ? b->lds_diet8 : b->lds_base + (size_t)TW * b->lds_per_wave;
   if (lds > 64 * 1024)
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -203,21 +208,22 @@ int launch_fill_affine_t(bialign_batch* b, const DeviceBatch& v, int first, int 
 
 // One-wave workgroups of the cross-CU kernel <S, LEAN> the device can hold at once, from the runtime's
 // occupancy calculation for the actual code object (registers, LDS): the cap of a cross-CU grid.
-template <int S, bool LEAN>
+template <int S, bool LEAN, int TW = 1>
 int xcu_resident_blocks(bialign_batch* b) {
-  int& cached = b->xcu_resident[LEAN ? 1 : 0];
+  int& cached = b->xcu_resident[(LEAN ? 1 : 0) + (TW == 8 ? 2 : 0)];
   if (cached >= 0) return cached;
   cached = 0;
-  if constexpr (S <= 3) {
-    auto kern = fill_affine_kernel<S, true, 1, true, false, LEAN>;
-    const size_t lds = b->lds_base + b->lds_per_wave;
+  if constexpr (S <= 3 && (TW == 1 || S == 2)) {
+    if (TW == 8 && !diet8_available(b)) return cached;
+    auto kern = fill_affine_kernel<S, true, TW, true, false, LEAN>;
+    const size_t lds = TW == 8 ? b->lds_diet8 : b->lds_base + b->lds_per_wave;
     if (lds > 64 * 1024 &&
         hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
       (void)hipGetLastError();
       return cached;
     }
     int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), 64, lds) != hipSuccess) {
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), 64 * TW, lds) != hipSuccess) {
       (void)hipGetLastError();
       return cached;
     }
@@ -234,7 +240,8 @@ int launch_fill_affine_l(bialign_batch* b, const DeviceBatch& v, int first, int 
                     : launch_fill_affine_t<S, false, 1, false, false, LEAN>(b, v, first, count, 1);
   }
   const bool xcu_ok = !b->dense && !b->no_xcu;
-  const TeamShape ts = team_shape(b, first, count, xcu_ok ? xcu_resident_blocks<S, LEAN>(b) : 0);
+  const TeamShape ts = team_shape(b, first, count, xcu_ok ? xcu_resident_blocks<S, LEAN>(b) : 0,
+                                  xcu_ok ? xcu_resident_blocks<S, LEAN, 8>(b) : 0);
   b->last_team = ts.waves() * (ts.gw > 1 ? -1 : 1);
   if (b->dense) {
     if constexpr (S <= 3) {
@@ -243,10 +250,13 @@ int launch_fill_affine_l(bialign_batch* b, const DeviceBatch& v, int first, int 
     b->last_team = 1;
     return launch_fill_affine_t<S, true, 1, false, true, LEAN>(b, v, first, count, 1);
   }
+  if constexpr (S == 2) {
+    if (ts.gw > 1 && ts.tw == 8) return launch_fill_affine_t<S, true, 8, true, false, LEAN>(b, v, first, count, ts.gw);
+  }
   if constexpr (S <= 3) {
     if (ts.gw > 1) return launch_fill_affine_t<S, true, 1, true, false, LEAN>(b, v, first, count, ts.gw);
   }
-  if constexpr (S <= 1) {
+  if constexpr (S <= 2) {  // (s=2: the DIET layout)
     if (ts.tw == 8) return launch_fill_affine_t<S, true, 8, false, false, LEAN>(b, v, first, count, 1);
   }
   if constexpr (S <= 3) {  // s >= 4 needs nearly all 512 registers of a SIMD lane: one wave per pair

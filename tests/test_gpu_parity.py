@@ -132,6 +132,16 @@ def test_cross_cu_team_full_layers(n, m, s, seed, team, monkeypatch):
     assert t["waves_per_pair"] == team and t["cross_cu"]
 
 
+@pytest.mark.parametrize("n,m,s,seed,team,hybrid", [(180, 440, 2, 51, 8, 0), (200, 470, 2, 52, 8, 1),
+                                                     (360, 810, 2, 53, 16, 2), (540, 1180, 2, 54, 24, 3)])
+def test_eight_wave_workgroups_s2_full_layers(n, m, s, seed, team, hybrid, monkeypatch):
+    """The s=2 sweep with eight waves per workgroup (two per SIMD; half-length ghost blocks, molecule A's
+    codes read from global memory), alone and as cross-CU teams of such workgroups: every layer cell."""
+    monkeypatch.setenv("BIALIGN_TEAM", ("h%d" % hybrid) if hybrid else "8")
+    t = full_layers_check(n, m, s, seed)
+    assert t["waves_per_pair"] == team and t["cross_cu"] == (hybrid > 1)
+
+
 def test_team_sweep_batch_matches_single_wave(monkeypatch):
     """Default policy picks two waves per pair for this batch; results equal the one-wave sweep."""
     from bialign_amd.batch import make_batch

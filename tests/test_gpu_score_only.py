@@ -39,7 +39,8 @@ def test_scores_equal_full_path_and_oracle(s, ov):
 @pytest.mark.parametrize("n,m,s,ov,team", [
     (300, 310, 1, {}, "2"), (130, 420, 1, {}, "2"), (420, 400, 0, {}, "2"), (150, 400, 2, {}, "4"),
     (330, 650, 1, {}, "x8"), (700, 1300, 1, {}, "x16"), (300, 320, 1, LIN, "2"), (200, 400, 2, LIN, "4"),
-    (330, 650, 1, LIN, "8"), (257, 129, 3, {}, None), (500, 480, 1, {}, None)])
+    (330, 650, 1, LIN, "8"), (257, 129, 3, {}, None), (500, 480, 1, {}, None),
+    (200, 470, 2, {}, "8"), (360, 810, 2, {}, "h2")])
 def test_multi_strip_and_team_shapes(n, m, s, ov, team, monkeypatch):
     if team:
         monkeypatch.setenv("BIALIGN_TEAM", team)
@@ -49,7 +50,7 @@ def test_multi_strip_and_team_shapes(n, m, s, ov, team, monkeypatch):
     np.testing.assert_array_equal(lean, full)
     assert tl["waves_per_pair"] == tf["waves_per_pair"] and tl["cross_cu"] == tf["cross_cu"]
     if team:
-        assert tl["waves_per_pair"] == int(team.lstrip("x"))
+        assert tl["waves_per_pair"] == (8 * int(team[1:]) if team[0] == "h" else int(team.lstrip("x")))
 
 
 def test_dense_mu2_score_only():
