@@ -56,9 +56,10 @@ struct BoolTag {
 //     after the stores it covers have left the wave's vector-memory queue.
 typedef int v3i __attribute__((ext_vector_type(3)));
 
+// wt (wave-uniform): write through to memory -- the records of a wave whose successor runs on another CU
 template <bool XCU>
-__device__ __forceinline__ void store_chunk(int32_t* p, v4i v) {
-  if (XCU)
+__device__ __forceinline__ void store_chunk(int32_t* p, v4i v, bool wt) {
+  if (XCU && wt)
     asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
   else
     *reinterpret_cast<v4i*>(p) = v;
@@ -204,16 +205,24 @@ __global__ void __launch_bounds__(64 * TW) fill_affine_kernel(const DeviceBatch 
   //      block whose last local step is h_last
   int blk_q = 0, blk_rem = 0;  // (next block start) div / mod P
   bool team_failed = false;
+  // Cross-CU teams of multi-wave workgroups: only the last wave of a workgroup hands over to another CU
+  // (its successor is wave 0 of the next workgroup): it alone writes through and publishes its progress in
+  // HBM; the others meet their successor in this workgroup's LDS and L2, like an in-workgroup team.
+  const bool to_other_cu = XCU && (TW == 1 || wl == TW - 1);   // this wave's records are read on another CU
+  // (Writing through the bottom lane row only -- all the successor replays -- was tried and is both slower,
+  //  54 -> 96 ms on a config-4 chunk, and wrong: lines then mix write-through and write-back sectors.)
+  const bool wt_lane = to_other_cu;
+  const bool from_other_cu = XCU && (TW == 1 || wl == 0);      // this wave's predecessor runs on another CU
   int32_t* const prog_glb = XCU ? A.prog + (int64_t)slot * 64 : nullptr;
   auto prog_get = [&](int idx) __attribute__((always_inline)) -> int {
-    if (XCU) return __hip_atomic_load(prog_glb + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return prog_lds[idx];
+    if (from_other_cu) return __hip_atomic_load(prog_glb + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return prog_lds[XCU ? wl - 1 : idx];
   };
   auto prog_put = [&](int v) __attribute__((always_inline)) {  // lane 0 only
-    if (XCU)
+    if (to_other_cu)
       __hip_atomic_store(prog_glb + w, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     else
-      prog_lds[w] = v;
+      prog_lds[XCU ? wl : w] = v;
   };
   int seen_prog = -0x40000000;  // the partner's progress as last read
   auto wait_partner = [&](int h_last) __attribute__((always_inline)) {
@@ -477,13 +486,13 @@ __global__ void __launch_bounds__(64 * TW) fill_affine_kernel(const DeviceBatch 
           if (4 * c + 3 >= bb * 9 && 4 * c + 3 < (bb + 1) * 9) {  // chunk c completes with this point
             v4i v;
             v.x = outv[4 * c]; v.y = outv[4 * c + 1]; v.z = outv[4 * c + 2]; v.w = outv[4 * c + 3];
-            store_chunk<XCU>(dst + c * R_::CH + slot * 4, v);
+            store_chunk<XCU>(dst + c * R_::CH + slot * 4, v, wt_lane);
           }
         }
         if (LEAN && bb == W - 1) {
 #pragma unroll
           for (int t = 0; t < TAIL; ++t) {
-            if (XCU)
+            if (wt_lane)
               __hip_atomic_store(dst + NCH4 * R_::CH + slot * TAIL + t, outv[4 * NCH4 + t], __ATOMIC_RELAXED,
                                  __HIP_MEMORY_SCOPE_AGENT);
             else
@@ -499,7 +508,7 @@ __global__ void __launch_bounds__(64 * TW) fill_affine_kernel(const DeviceBatch 
           const int tslot = (live && !ghost) ? L - W : R_::SL + (L < W ? L : W + (L - R * W));
 #pragma unroll
           for (int t = 0; t < TAIL; ++t) {
-            if (XCU)
+            if (wt_lane)
               __hip_atomic_store(dst + NCH4 * R_::CH + tslot * TAIL + t, outv[4 * NCH4 + t], __ATOMIC_RELAXED,
                                  __HIP_MEMORY_SCOPE_AGENT);
             else
