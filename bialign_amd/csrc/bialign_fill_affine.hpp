@@ -276,8 +276,9 @@ __global__ void __launch_bounds__(64 * TW) fill_affine_kernel(const DeviceBatch 
     const int gt = g & (GF::BLK - 1), ghalf = (g / GF::BLK) & 1;
     if (gt == 0) {
       GF::wait_block(vm_younger);
-      // all stores of steps before the block just finished are acknowledged (BLK <= 8)
-      if ((XCU || TW > 1) && L == 0) prog_put(g - 8);
+      // the DMAs just retired were issued at step g - BLK ahead of that step's stores, and vmcnt retires in
+      // order: the stores of all steps before g - BLK are acknowledged
+      if ((XCU || TW > 1) && L == 0) prog_put(g - GF::BLK);
       prefetch_block(g + GF::BLK, ghalf ^ 1, jj + GF::BLK);
       vm_younger = 0;
     }

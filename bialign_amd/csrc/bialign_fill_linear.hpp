@@ -145,7 +145,7 @@ __global__ void __launch_bounds__(64 * TW) fill_linear_kernel(const DeviceBatch 
     const int gt = g & (GF::BLK - 1), ghalf = (g / GF::BLK) & 1;
     if (gt == 0) {
       GF::wait_block(vm_younger);
-      if (T > 1 && L == 0) prog[w] = g - 8;
+      if (T > 1 && L == 0) prog[w] = g - GF::BLK;  // see the affine kernel
       prefetch_block(g + GF::BLK, ghalf ^ 1, jj + GF::BLK);
       vm_younger = 0;
     }
