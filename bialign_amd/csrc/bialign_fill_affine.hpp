@@ -369,13 +369,26 @@ __global__ void __launch_bounds__(64 * TW) fill_affine_kernel(const DeviceBatch 
                           (INTERIOR || __builtin_amdgcn_ballot_w64(tile_act && !ghost) != 0) &&
                           ((!XCU && TW == 1) || rec <= rec_last);
     const int slot = LEAN ? aa : (pad_lane ? R_::SL + pad_idx : L - W);  // storage slot of this lane
-    if (__builtin_amdgcn_ballot_w64(do_store) != 0) vm_younger += GF::STORES_PER_STEP;
+    if (__builtin_amdgcn_ballot_w64(do_store) != 0)
+      vm_younger += (BIALIGN_EXP == 5 && INTERIOR && !LEAN) ? (2 + ND + 7) / 8 : GF::STORES_PER_STEP;
     int32_t* const dst = BIALIGN_EXP == 2
                              ? A.layers + ((int64_t)(blockIdx.x & 255) << 18) + (int64_t)(g & 31) * RECDW
                              : sto + (int64_t)rec * RECDW;
 
     // ---- 3. the W lattice points of this (i, j, a)
     int outv[ND];
+    // BIALIGN_EXP 5 (timing build): interior steps store base + 16-bit deltas, 16 dwords
+    // per lane at s=1 instead of 27, with the real encoding arithmetic and a stand-in for the ghost decode
+    constexpr bool PK = BIALIGN_EXP == 5 && INTERIOR && !LEAN;
+    constexpr int PK_NCH = (2 + ND + 7) / 8;  // 16-byte chunks of a packed lane record
+    int pk_base = 0, pk_acc = 0, pk_e[PK ? ND : 1];
+    if (PK) {
+      int gb = ghostM[0];
+#pragma unroll
+      for (int d = 1; d < ND; ++d)  // ghost rows would be decoded: one SDWA add per value
+        asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0"
+            : "=v"(ghostM[d]) : "v"(gb), "v"(ghostM[d]));
+    }
     int h2y[3] = {SENT, SENT, SENT};  // H2[U][Y] of point bb-1 (same step, same lane)
 #pragma unroll
     for (int bb = 0; bb < W; ++bb) {
@@ -481,7 +494,43 @@ __global__ void __launch_bounds__(64 * TW) fill_affine_kernel(const DeviceBatch 
           A.scores[pid] = best;
         }
       }
-      if (do_store) {
+      if (PK) {
+        if (bb == 0) pk_base = M[8] - 0x8000;
+#pragma unroll
+        for (int q = 0; q < 9; ++q) {
+          int e = M[q] - pk_base;
+          if (can_be_empty<W>(q / 3, q % 3, bb)) {
+            const bool ng = M[q] == NEG;
+            pk_acc |= ng ? 0 : e;
+            e = ng ? 0xffff : e;
+          } else {
+            pk_acc |= e;
+          }
+          pk_e[PK ? bb * 9 + q : 0] = e;
+        }
+        if (do_store) {
+          int32_t* const dstc = sto + (int64_t)rec * (PK_NCH * R_::CH);
+#pragma unroll
+          for (int c = 0; c < PK_NCH; ++c) {
+            const int last = 8 * c + 5 < ND - 1 ? 8 * c + 5 : ND - 1;  // last value index of chunk c
+            if (last >= bb * 9 && last < (bb + 1) * 9) {
+              int dw[4];
+#pragma unroll
+              for (int x = 0; x < 4; ++x) {
+                const int d = 4 * c + x;  // dword of the lane record: 0 = base, then value pairs
+                const int lo = 2 * d - 2, hi = 2 * d - 1;
+                dw[x] = d == 0 ? pk_base
+                               : ((lo < ND ? pk_e[PK && lo < ND ? lo : 0] & 0xffff : 0) | (hi < ND ? pk_e[PK && hi < ND ? hi : 0] << 16 : 0));
+              }
+              v4i v;
+              v.x = dw[0]; v.y = dw[1]; v.z = dw[2]; v.w = dw[3];
+              store_chunk<XCU>(dstc + c * R_::CH + slot * 4, v, wt_lane);
+            }
+          }
+        }
+        if (bb == W - 1 && act_row && !ghost && (unsigned)pk_acc > 0xffffu) A.scores[pid] = 0;  // (the real thing: fall back)
+      }
+      if (do_store && !PK) {
 #pragma unroll
         for (int c = 0; c < NCH4; ++c) {
           if (4 * c + 3 >= bb * 9 && 4 * c + 3 < (bb + 1) * 9) {  // chunk c completes with this point
@@ -501,7 +550,7 @@ __global__ void __launch_bounds__(64 * TW) fill_affine_kernel(const DeviceBatch 
           }
         }
       }
-      if (!LEAN && bb == W - 1) {
+      if (!LEAN && bb == W - 1 && !PK) {
         // the tail is stored by ALL 64 lanes (Rec::TAILSLOTS): the spare ones fill the record up to its end
         const bool wave_stores = BIALIGN_EXP != 1 && (INTERIOR || __builtin_amdgcn_ballot_w64(tile_act && !ghost) != 0) &&
                                  ((!XCU && TW == 1) || rec <= rec_last);
