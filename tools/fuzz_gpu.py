@@ -13,7 +13,7 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 12345)
 t_end = time.time() + budget
 cases = pairs_done = 0
 while time.time() < t_end:
-    s = int(rng.integers(0, 6))
+    s = int(rng.integers(0, 6)) if rng.random() < 0.85 else int(rng.integers(6, 11))   # 6..10: the wide-band path
     affine = bool(rng.integers(0, 4))           # 3/4 affine
     beta = int(rng.integers(-400, 80)) if affine else 0
     if affine and beta == 0:
@@ -22,13 +22,15 @@ while time.time() < t_end:
                   shift_cost=int(rng.integers(-400, 1)), structure_weight=int(rng.integers(0, 1200)))
     npairs = int(rng.integers(1, 9))
     big = rng.random() < float(os.environ.get("FUZZ_BIG", 0.15))   # multi-strip / team-capable shapes
-    hi = 420 if big else 90
+    hi = (420 if big else 90) if s <= 5 else (60 if big else 28)
+    if s == 2 and big and rng.random() < 0.5:
+        hi, npairs = 900, min(npairs, 2)                              # room for eight-wave workgroups and teams of them
     shapes = [(int(rng.integers(1, hi)), int(rng.integers(1, hi))) for _ in range(npairs)]
     pairs = [synth.protein_pair(int(rng.integers(1 << 30)), n, m) for n, m in shapes]
     dense = rng.random() < 0.3
     tabs = [rng.integers(-500, 1500, size=(n, m)).astype(np.int32) for n, m in shapes] if dense else None
-    mode = ["full", "score_only", "lean_trace"][int(rng.integers(0, 3))]
-    team = str(rng.choice(["", "", "2", "4", "8", "x2", "x3", "x5", "x8"]))
+    mode = ["full", "score_only", "lean_trace"][int(rng.integers(0, 3))] if s <= 5 else "full"
+    team = str(rng.choice(["", "", "2", "4", "8", "x2", "x3", "x5", "x8", "h1", "h2"]))
     os.environ.pop("BIALIGN_TEAM", None)
     if team:
         os.environ["BIALIGN_TEAM"] = team
