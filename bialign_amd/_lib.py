@@ -56,7 +56,7 @@ class Timing(ctypes.Structure):
     _fields_ = [("fill_ms", ctypes.c_double), ("traceback_ms", ctypes.c_double),
                 ("fill_launches", ctypes.c_int32), ("traceback_launches", ctypes.c_int32),
                 ("waves_per_pair", ctypes.c_int32), ("cross_cu", ctypes.c_int32),
-                ("recovered_runs", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+                ("recovered_runs", ctypes.c_int32), ("packed_records", ctypes.c_int32)]
 
 
 #: every symbol include/bialign.h declares: (name, restype, argtypes)

@@ -279,7 +279,7 @@ int launch_dump_any(const bialign_batch* b, const DeviceBatch& v, int pid, int32
 int check_device_error(const bialign_batch* b) {
   int32_t err = 0;
   HIP_TRY(hipMemcpy(&err, b->d_err.p, sizeof err, hipMemcpyDeviceToHost));
-  if (err) return fail(BIALIGN_E_DEVICE, "fill kernel: team hand-off timed out (device error flag %d)", err);
+  if (err) return fail(BIALIGN_E_DEVICE, "fill kernel: device error flag %d (1 = team hand-off timed out)", err);
   return BIALIGN_OK;
 }
 
@@ -429,6 +429,23 @@ int bialign_batch_create(bialign_engine* eng, const bialign_params* prm, const b
     return fail(BIALIGN_E_UNSUPPORTED, "molecules too long for the LDS staging (%zu bytes needed, 160 KiB per workgroup)",
                 std::max(b->lds_bytes, b->lds_trace));
 
+  // ---- packed records (Pack<S>): for sweeps whose steps are mostly interior
+  {
+    const char* e = getenv("BIALIGN_PACK");  // "0" never, "1" wherever the layout allows (tests), unset: when it pays
+    const bool force = e && e[0] == '1';
+    bool ok = b->affine && (S == 1 || S == 2) && !b->dense && !b->lean && prm->gap_opening_cost <= 0 && !(e && e[0] == '0') &&
+              (force || colmax < 8192);  // offsets span a few column scores (measured: up to 2.5): beyond this they will not fit
+    for (int p = 0; ok && p < pr->npairs; ++p) {
+      const PairDesc& d = b->pairs[p];
+      const int interior = d.m - S - (S == 1 ? Pack<1>::LO : Pack<2>::LO) + 1;  // phases LO .. m - S per strip
+      const int64_t packed_dw = S == 1 ? Pack<1>::written_dwords(d.G, d.P, d.m) : Pack<2>::written_dwords(d.G, d.P, d.m);
+      const int64_t full_dw = (int64_t)d.G * (S == 1 ? Rec<1, 9>::RECDW : Rec<2, 9>::RECDW);
+      // unless forced (tests): only where it saves a fifth of the bytes written (long enough columns, more than a strip or two)
+      ok = interior >= 1 && (force || packed_dw * 5 <= full_dw * 4);
+    }
+    b->pack = ok;
+  }
+
   // ---- chunking under the HBM budget; inside a chunk longest sweeps first
   size_t free_b = 0, total_b = 0;
   HIP_TRY(hipMemGetInfo(&free_b, &total_b));
@@ -451,6 +468,8 @@ int bialign_batch_create(bialign_engine* eng, const bialign_params* prm, const b
       const int64_t scratch_dw = (int64_t)(d.m + 2 * (64 / W - 1) + W) * full_rec;  // one strip: m + MAXOFF + 1 records
       d.scratch_off = lean_dw;  // relative to layer_off until the chunk layout is fixed below
       pair_dwords[p] = b->lean_trace ? lean_dw + b->resw_k * scratch_dw : (b->lean ? lean_dw : (int64_t)d.G * full_rec);
+      if (b->pack)  // room for either form: a sweep that meets an unpackable value is repeated with full records
+        pair_dwords[p] = std::max(pair_dwords[p], S == 1 ? Pack<1>::pair_dwords(d.G, d.P, d.m) : Pack<2>::pair_dwords(d.G, d.P, d.m));
     }
   };
   // lean traceback: few pairs -> several strips per round (they re-sweep in parallel), as memory allows
@@ -649,7 +668,7 @@ static int enqueue_run(bialign_batch* b, uint32_t flags) {
   hipStream_t st = b->eng->stream;
   b->timing = bialign_timing{};
   b->ran = b->ran_trace = false;
-  b->used_xcu = false;
+  b->used_xcu = b->used_pack = false;
   const int nchunks = (int)b->chunk_begin.size() - 1;
   while ((int)b->evs.size() < 3 * nchunks) {
     hipEvent_t e = nullptr;
@@ -701,16 +720,27 @@ int bialign_batch_wait(bialign_batch* b) {
     int32_t err = 0;
     HIP_TRY(hipMemcpy(&err, b->d_err.p, sizeof err, hipMemcpyDeviceToHost));
     if (!err) break;
-    // A cross-CU team lost co-residency (its waves spin on partners that were never scheduled:
-    // another tenant holds wave slots).  The run is repeated once with in-workgroup teams, which
-    // depend on nobody; the batch stays on them.
-    if (!b->used_xcu || b->no_xcu)
-      return fail(BIALIGN_E_DEVICE, "fill kernel: team hand-off timed out (device error flag %d)", err);
-    b->no_xcu = true;
+    // Bit 1: a cross-CU team lost co-residency (its waves spin on partners that were never scheduled:
+    // another tenant holds wave slots) -- the run is repeated with in-workgroup teams, which depend on
+    // nobody.  Bit 2: a packed record met a value that does not fit its 16-bit offset -- the run is
+    // repeated with full records.  Either way the batch stays on the safe form.
+    bool again = false;
+    if (err & 1) {
+      if (!b->used_xcu || b->no_xcu)
+        return fail(BIALIGN_E_DEVICE, "fill kernel: team hand-off timed out (device error flag %d)", err);
+      b->no_xcu = again = true;
+    }
+    if (err & 2) {
+      if (!b->used_pack || b->pack_failed)
+        return fail(BIALIGN_E_DEVICE, "fill kernel: device error flag %d", err);
+      b->pack_failed = again = true;
+    }
+    if (!again) return fail(BIALIGN_E_DEVICE, "fill kernel: device error flag %d", err);
     ++b->recovered;
     if (int rc = enqueue_run(b, b->pending_flags)) return rc;
   }
   b->timing.recovered_runs = b->recovered;
+  b->timing.packed_records = b->used_pack ? 1 : 0;
   b->ran = true;
   b->ran_trace = b->pending_trace;
   return BIALIGN_OK;
@@ -767,13 +797,16 @@ int bialign_batch_dump_layers(bialign_batch* b, int32_t pair, int32_t* out) {
   const int pos = (int)(std::find(b->order.begin(), b->order.end(), pair) - b->order.begin());
   DeviceBatch v = b->view();
   HIP_TRY(hipMemsetAsync(b->d_err.p, 0, sizeof(int32_t), st));
-  b->used_xcu = false;
+  b->used_xcu = b->used_pack = false;
   int rc = launch_fill(b, v, pos, 1);
   if (rc) return rc;
-  if (b->used_xcu && !b->no_xcu) {  // a cross-CU team that lost co-residency: once more, in one workgroup
+  if ((b->used_xcu && !b->no_xcu) || (b->used_pack && !b->pack_failed)) {  // forms a launch can fall back from, as in a run
     HIP_TRY(hipStreamSynchronize(st));
-    if (check_device_error(b) != BIALIGN_OK) {
-      b->no_xcu = true;
+    int32_t err = 0;
+    HIP_TRY(hipMemcpy(&err, b->d_err.p, sizeof err, hipMemcpyDeviceToHost));
+    if (err) {
+      if (err & 1) b->no_xcu = true;
+      if (err & 2) b->pack_failed = true;
       ++b->recovered;
       HIP_TRY(hipMemsetAsync(b->d_err.p, 0, sizeof(int32_t), st));
       rc = launch_fill(b, v, pos, 1);

@@ -6,7 +6,7 @@ namespace bialign {
 // ---------------------------------------------------------------------------
 // Layer dump in the reference layout (tests only).
 // ---------------------------------------------------------------------------
-template <int S, int NL>
+template <int S, int NL, bool PACK = false>
 __global__ void dump_layers_kernel(const DeviceBatch A, int pid, int32_t* out) {
   constexpr int W = 2 * S + 1;
   const PairDesc pd = A.pairs[pid];
@@ -19,7 +19,7 @@ __global__ void dump_layers_kernel(const DeviceBatch A, int pid, int32_t* out) {
     const int k = i + aa - S, l = j + bb - S;
     const bool ok = k >= 0 && k <= n && l >= 0 && l <= m;
     for (int q = 0; q < NL; ++q)
-      out[q * cells + t] = ok ? A.layers[cell_dword<S, NL>(pd, i, j, aa, bb, q)] : 0;
+      out[q * cells + t] = !ok ? 0 : (PACK ? packed_cell<S>(A.layers, pd, i, j, aa, bb, q) : A.layers[cell_dword<S, NL>(pd, i, j, aa, bb, q)]);
   }
 }
 

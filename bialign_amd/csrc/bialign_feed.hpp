@@ -65,6 +65,42 @@ struct GhostFeed {
           : "memory");
     }
   }
+  // The same for a sweep with packed records (Pack<S>): the source of a piece is the packed record of an
+  // interior step (NCH pieces per lane; the surplus lanes of a round re-read piece 0) or the full record of
+  // any other step in the pair's second region (starting at dword bnd_off).  Not used by re-sweeps (Qbase = 0).
+  __device__ static __forceinline__ void issue_packed(const int32_t* lay, int64_t bnd_off, int m, int h0, int blk_q,
+                                                      int blk_rem, int P, int T, int w, int rec_last, int lane,
+                                                      uint32_t lds_base) {
+    using PK = Pack<S>;
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+      const int q = min(r * 64 + lane, NPIECE - 1);
+      const int t = q / (W * NP), rem = q - t * (W * NP);
+      const int aa = rem / NP, c = rem - aa * NP;
+      const int xr = blk_rem + t - aa;
+      const int ql = blk_q + (xr >= P ? 1 : 0) - (xr < 0 ? 1 : 0);
+      const int jj = xr - (xr >= P ? P : 0) + (xr < 0 ? P : 0);  // the ghost lane's column
+      const int ts = jj + 2 * (R - 1) + aa;                      // the bottom lane row of the strip above was there at this t
+      const int cs = ts >= P ? ts - P : ts, qs = ql * T + w - 1 + (ts >= P ? 1 : 0);
+      const int64_t rec = (int64_t)(ql * T + w - 1) * P + ts;
+      const bool valid = rec >= 0 && rec <= rec_last;
+      const int sl = (R - 2) * W + aa;  // storage slot of the bottom real row
+      const int32_t* p;
+      if (valid && PK::interior(qs, cs, m))
+        p = lay + rec * PK::RECDW + (c < PK::NCH ? c : 0) * R_::CH + sl * 4;
+      else
+        p = lay + bnd_off + (valid ? PK::bidx(qs, cs, P, m) : 0) * R_::RECDW +
+            (c < R_::NCH4 ? c * R_::CH + sl * 4 : R_::NCH4 * R_::CH + sl * R_::TAIL);
+      const uint32_t dst = lds_base + r * 1024;
+      uint32_t keep;
+      asm volatile(
+          "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+          "global_load_lds_dwordx4 %1, off sc1\n\ts_mov_b32 m0, %0"
+          : "=&s"(keep)
+          : "v"(p), "s"(dst)
+          : "memory");
+    }
+  }
   // Store instructions a storing step issues at least (chunks + tail), i.e. vector-memory
   // operations younger than the block's DMAs that each such step adds.
   static constexpr int STORES_PER_STEP = R_::NCH4 + (R_::TAIL ? 1 : 0);

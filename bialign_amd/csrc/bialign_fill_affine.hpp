@@ -70,8 +70,12 @@ __device__ __forceinline__ void store_chunk(int32_t* p, v4i v, bool wt) {
 //   within the strip).  Workgroup b handles pair b / K, strip TraceState::strip - b % K (K =
 //   A.resw_k strips per round, independent of each other, each into its own scratch slot); the
 //   strip the walk stands in is swept only up to the walk's column.  One wave per strip.
-template <int S, bool BETA_NONPOS, int TW, bool XCU, bool DENSE = false, bool LEAN = false, bool RESW = false>
+//   PACK: interior steps store packed records, the others full records in the pair's second region (Pack<S>).
+template <int S, bool BETA_NONPOS, int TW, bool XCU, bool DENSE = false, bool LEAN = false, bool RESW = false,
+          bool PACK = false>
 __global__ void __launch_bounds__(64 * TW) fill_affine_kernel(const DeviceBatch A) {
+  static_assert(!PACK || (!LEAN && !RESW && S >= 1), "packed records: full-storage sweeps with a band");
+  using PK_ = Pack<S>;
   static_assert(!XCU || TW == 1 || TW == 8, "cross-CU teams are built from one-wave or eight-wave workgroups");
   // DIET (eight waves of the s=2 kernel in one workgroup = two per SIMD on a whole CU): their arrays fit
   // 160 KB of LDS only with half-length ghost blocks and molecule A's codes left in global memory (they
@@ -153,6 +157,10 @@ __global__ void __launch_bounds__(64 * TW) fill_affine_kernel(const DeviceBatch 
   int32_t* const lay = A.layers + pd.layer_off;                       // records the ghost feed replays
   int32_t* const sto = RESW ? A.scratch + pd.scratch_off + (int64_t)kk * (m + G_::MAXOFF + 1) * RECDW : lay;  // records this sweep writes
 
+  const int64_t pk_bnd_off = (int64_t)pd.G * PK_::RECDW;  // PACK: the pair's full records follow its packed ones
+  static_assert(!PACK || (pack_corner(W, 3, 0) == can_be_empty<W>(1, 0, 0) && pack_corner(W, 4, 0) == can_be_empty<W>(1, 1, 0) &&
+                          pack_corner(W, 1, W - 1) == can_be_empty<W>(0, 1, W - 1) && pack_corner(W, 8, W - 1) == can_be_empty<W>(2, 2, W - 1)),
+                "pack_corner mirrors can_be_empty");
   const int rec_last = pd.G - 1;     // last record of this pair
   // local steps of this wave: its strips are w, w+T, ... (NSw of them)
   const int NSw = RESW ? 1 : (pd.NS - w + T - 1) / T;
@@ -235,7 +243,7 @@ __global__ void __launch_bounds__(64 * TW) fill_affine_kernel(const DeviceBatch 
     // bounded spin: a protocol bug must surface as an error, never as a hung GPU
     for (int spin = 0; (seen_prog = prog_get(src)) < need; ++spin) {
       if (spin > A.spin_limit) {  // ~1 s by default; then fail fast: no further waits, the host recovers or reports
-        if (L == 0) atomicExch(A.errflag, 1);
+        if (L == 0) atomicOr(A.errflag, 1);
         team_failed = true;
         break;
       }
@@ -253,7 +261,10 @@ __global__ void __launch_bounds__(64 * TW) fill_affine_kernel(const DeviceBatch 
     // h0 = first local step of the block (this lane is then at column jj0, before wrapping);
     // blk_q/blk_rem describe h0
     wait_partner(h0 + GF::BLK - 1);
-    GF::issue(lay, h0 + Qbase * P, blk_q, blk_rem, P, T, w, GOFF, rec_last, L, ring_lds + half * GF::SLOTS * 16);
+    if (PACK)
+      GF::issue_packed(lay, pk_bnd_off, m, h0, blk_q, blk_rem, P, T, w, rec_last, L, ring_lds + half * GF::SLOTS * 16);
+    else
+      GF::issue(lay, h0 + Qbase * P, blk_q, blk_rem, P, T, w, GOFF, rec_last, L, ring_lds + half * GF::SLOTS * 16);
     if (DENSE) MF::issue(mu2tab, n, m, P, jj0, Qbase + strip, T, w, il, aa, mu2_lds + half * MF::BLK * 256);
     blk_rem += GF::BLK;
     if (blk_rem >= P) { blk_rem -= P; ++blk_q; }
@@ -283,6 +294,23 @@ __global__ void __launch_bounds__(64 * TW) fill_affine_kernel(const DeviceBatch 
       vm_younger = 0;
     }
     GF::fetch(ghostM, ring + ghalf * GF::SLOTS, gt, aa);
+    if (PACK) {  // the ghost row replays record (c + 2(R-1)) of the strip above: packed if that step was interior
+      const int c0 = __builtin_amdgcn_readfirstlane(jj), q0 = __builtin_amdgcn_readfirstlane(strip);
+      const int ts = c0 + 2 * (R - 1), over = ts >= P ? 1 : 0;
+      if (PK_::interior(q0 * T + w - 1 + over, ts - over * P, m)) {
+        int raw[4 * PK_::NCH];
+#pragma unroll
+        for (int k = 0; k < 4 * PK_::NCH; ++k) raw[k] = ghostM[k < ND ? k : 0];
+#pragma unroll
+        for (int d = 0; d < ND; ++d) {
+          const int h = 2 + d;
+          const unsigned word = (unsigned)raw[h >> 1];
+          const unsigned e = (h & 1) ? word >> 16 : word & 0xffffu;
+          const int v = raw[0] + (int)e;
+          ghostM[d] = pack_corner(W, d % 9, d / 9) ? (e == 0xffffu ? NEG : v) : v;
+        }
+      }
+    }
 
     // ---- 1. exchange reads: what the three source lanes published last step.  Rows of band
     //         column r are first needed by point r-1, so they are fetched two points ahead
@@ -369,26 +397,20 @@ __global__ void __launch_bounds__(64 * TW) fill_affine_kernel(const DeviceBatch 
                           (INTERIOR || __builtin_amdgcn_ballot_w64(tile_act && !ghost) != 0) &&
                           ((!XCU && TW == 1) || rec <= rec_last);
     const int slot = LEAN ? aa : (pad_lane ? R_::SL + pad_idx : L - W);  // storage slot of this lane
-    if (__builtin_amdgcn_ballot_w64(do_store) != 0)
-      vm_younger += (BIALIGN_EXP == 5 && INTERIOR && !LEAN) ? (2 + ND + 7) / 8 : GF::STORES_PER_STEP;
-    int32_t* const dst = BIALIGN_EXP == 2
-                             ? A.layers + ((int64_t)(blockIdx.x & 255) << 18) + (int64_t)(g & 31) * RECDW
-                             : sto + (int64_t)rec * RECDW;
+    if (__builtin_amdgcn_ballot_w64(do_store) != 0) vm_younger += (PACK && INTERIOR) ? PK_::NCH : GF::STORES_PER_STEP;
+    int32_t* dst = BIALIGN_EXP == 2
+                       ? A.layers + ((int64_t)(blockIdx.x & 255) << 18) + (int64_t)(g & 31) * RECDW
+                       : sto + (int64_t)rec * RECDW;
+    int32_t* const dstp = lay + (int64_t)rec * PK_::RECDW;  // PACK, interior steps: the packed record
+    if (PACK && !INTERIOR) {  // full record of a non-interior step: the pair's second region, by (step-strip, phase)
+      const int tl = jj + 2 * il + aa;  // = rec - (lane's strip) * P
+      const int over = tl >= P ? 1 : 0;
+      dst = lay + pk_bnd_off + PK_::bidx(strip * T + w + over, tl - over * P, P, m) * RECDW;
+    }
 
     // ---- 3. the W lattice points of this (i, j, a)
     int outv[ND];
-    // BIALIGN_EXP 5 (timing build): interior steps store base + 16-bit deltas, 16 dwords
-    // per lane at s=1 instead of 27, with the real encoding arithmetic and a stand-in for the ghost decode
-    constexpr bool PK = BIALIGN_EXP == 5 && INTERIOR && !LEAN;
-    constexpr int PK_NCH = (2 + ND + 7) / 8;  // 16-byte chunks of a packed lane record
-    int pk_base = 0, pk_acc = 0, pk_e[PK ? ND : 1];
-    if (PK) {
-      int gb = ghostM[0];
-#pragma unroll
-      for (int d = 1; d < ND; ++d)  // ghost rows would be decoded: one SDWA add per value
-        asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0"
-            : "=v"(ghostM[d]) : "v"(gb), "v"(ghostM[d]));
-    }
+    int pk_base = 0, pk_acc = 0, pk_e[PACK ? ND : 1];  // packed records: base, OR of the stored offsets, the offsets
     int h2y[3] = {SENT, SENT, SENT};  // H2[U][Y] of point bb-1 (same step, same lane)
 #pragma unroll
     for (int bb = 0; bb < W; ++bb) {
@@ -494,43 +516,48 @@ __global__ void __launch_bounds__(64 * TW) fill_affine_kernel(const DeviceBatch 
           A.scores[pid] = best;
         }
       }
-      if (PK) {
+      if (PACK && INTERIOR) {
+        // Packed record (Pack<S>): dword 0 = base, then the ND offsets as unsigned halfwords.  The OR of
+        // all offsets stored by lanes that hold lattice points is range-checked at the end of the step.
         if (bb == 0) pk_base = M[8] - 0x8000;
 #pragma unroll
         for (int q = 0; q < 9; ++q) {
           int e = M[q] - pk_base;
-          if (can_be_empty<W>(q / 3, q % 3, bb)) {
+          if (pack_corner(W, q, bb)) {
             const bool ng = M[q] == NEG;
             pk_acc |= ng ? 0 : e;
             e = ng ? 0xffff : e;
           } else {
             pk_acc |= e;
           }
-          pk_e[PK ? bb * 9 + q : 0] = e;
+          pk_e[PACK ? bb * 9 + q : 0] = e;
         }
         if (do_store) {
-          int32_t* const dstc = sto + (int64_t)rec * (PK_NCH * R_::CH);
 #pragma unroll
-          for (int c = 0; c < PK_NCH; ++c) {
-            const int last = 8 * c + 5 < ND - 1 ? 8 * c + 5 : ND - 1;  // last value index of chunk c
+          for (int c = 0; c < PK_::NCH; ++c) {
+            const int last = 8 * c + 5 < ND - 1 ? 8 * c + 5 : ND - 1;  // last value of chunk c
             if (last >= bb * 9 && last < (bb + 1) * 9) {
               int dw[4];
 #pragma unroll
               for (int x = 0; x < 4; ++x) {
-                const int d = 4 * c + x;  // dword of the lane record: 0 = base, then value pairs
+                const int d = 4 * c + x;  // dword of the lane record
                 const int lo = 2 * d - 2, hi = 2 * d - 1;
                 dw[x] = d == 0 ? pk_base
-                               : ((lo < ND ? pk_e[PK && lo < ND ? lo : 0] & 0xffff : 0) | (hi < ND ? pk_e[PK && hi < ND ? hi : 0] << 16 : 0));
+                               : ((lo < ND ? pk_e[PACK && lo < ND ? lo : 0] & 0xffff : 0) |
+                                  (hi < ND ? pk_e[PACK && hi < ND ? hi : 0] << 16 : 0));
               }
               v4i v;
               v.x = dw[0]; v.y = dw[1]; v.z = dw[2]; v.w = dw[3];
-              store_chunk<XCU>(dstc + c * R_::CH + slot * 4, v, wt_lane);
+              store_chunk<XCU>(dstp + c * R_::CH + slot * 4, v, wt_lane);
             }
           }
         }
-        if (bb == W - 1 && act_row && !ghost && (unsigned)pk_acc > 0xffffu) A.scores[pid] = 0;  // (the real thing: fall back)
+        if (bb == W - 1) {  // an offset that does not fit 16 bits (or collides with the -2^30 mark): the host falls back
+          const bool bad = act_row && !ghost && live && (unsigned)pk_acc >= 0xffffu;
+          if (__builtin_amdgcn_ballot_w64(bad) != 0 && L == 0) atomicOr(A.errflag, 2);
+        }
       }
-      if (do_store && !PK) {
+      if (do_store && !(PACK && INTERIOR)) {
 #pragma unroll
         for (int c = 0; c < NCH4; ++c) {
           if (4 * c + 3 >= bb * 9 && 4 * c + 3 < (bb + 1) * 9) {  // chunk c completes with this point
@@ -550,7 +577,7 @@ __global__ void __launch_bounds__(64 * TW) fill_affine_kernel(const DeviceBatch 
           }
         }
       }
-      if (!LEAN && bb == W - 1 && !PK) {
+      if (!LEAN && bb == W - 1 && !(PACK && INTERIOR)) {
         // the tail is stored by ALL 64 lanes (Rec::TAILSLOTS): the spare ones fill the record up to its end
         const bool wave_stores = BIALIGN_EXP != 1 && (INTERIOR || __builtin_amdgcn_ballot_w64(tile_act && !ghost) != 0) &&
                                  ((!XCU && TW == 1) || rec <= rec_last);
@@ -654,9 +681,12 @@ __global__ void __launch_bounds__(64 * TW) fill_affine_kernel(const DeviceBatch 
 
   // Two separate loops (not one loop with a branch inside): each keeps its loop-carried
   // registers where it likes; values only move at the rare hand-overs between runs.
+  // Interior steps by record number (Pack<S>::interior; lane 0 = ghost row, a = -s, carries the wave's phase):
+  // phase c in [LO, m - S] puts every lane inside the molecule columns with all its band points, strip >= Q0
+  // puts every lane row at i >= S + 1.  Readers of packed records apply the same rule to find a cell.
   auto all_interior = [&]() __attribute__((always_inline)) {
-    const bool lane_interior = !live || (jj >= S + 1 && jj <= m && i >= S + 1);
-    return __builtin_amdgcn_ballot_w64(lane_interior) == ~0ull;
+    const int c0 = __builtin_amdgcn_readfirstlane(jj), q0 = __builtin_amdgcn_readfirstlane(strip);
+    return PK_::interior(Qbase + q0 * T + w, c0, m);
   };
   int g = 0;  // local step of this wave
   while (g < H) {

@@ -116,7 +116,7 @@ __global__ void __launch_bounds__(64 * TW) fill_linear_kernel(const DeviceBatch 
     const int need = h_last + 2 * (R - 1) + 1 - (w == 0 ? P : 0);
     for (int spin = 0; prog[src] < need; ++spin) {
       if (spin > A.spin_limit) {
-        if (L == 0) atomicExch(A.errflag, 1);
+        if (L == 0) atomicOr(A.errflag, 1);
         team_failed = true;
         break;
       }

@@ -115,6 +115,13 @@ struct bialign_batch {
   int recovered = 0;       // runs repeated after a hand-off timeout
   int xcu_spin_limit = 1 << 20;  // polls before a cross-CU wave gives up (~1 s); BIALIGN_XCU_SPIN_LIMIT: tests
   uint32_t pending_flags = 0;
+  // Packed records (Pack<S>, bialign_types.hpp): decided per batch at creation (affine, max_shift 1 or 2, LOOKUP,
+  // full storage, beta <= 0, every pair long enough that most steps are interior); dropped for good when a sweep
+  // meets an offset that does not fit 16 bits (device flag bit 2 -> the run is repeated with full records).
+  bool pack = false, pack_failed = false;
+  bool used_pack = false;       // a fill launch of the pending / last run stored packed records
+  bool packed_layers = false;   // ... and so did the launch whose layers are in the buffer now
+  bool pack_now() const { return pack && !pack_failed; }
   DevBuf<uint8_t> d_seq_a, d_cls_a, d_seq_b, d_cls_b, d_trace;
   DevBuf<int32_t> d_mu2;  // dense-mu2 mode: all pairs' n x m tables
   bool dense = false;
@@ -178,12 +185,14 @@ inline bool diet8_available(const bialign_batch* b) {  // the eight-wave s=2 aff
 int xcu_serial_begin(bialign_engine* e);
 int xcu_serial_end(bialign_engine* e);
 
-template <int S, bool BETA_NONPOS, int TW, bool XCU, bool DENSE = false, bool LEAN = false>
+template <int S, bool BETA_NONPOS, int TW, bool XCU, bool DENSE = false, bool LEAN = false, bool PACK = false>
 int launch_fill_affine_t(bialign_batch* b, const DeviceBatch& v, int first, int count, int gw) {
   DeviceBatch w = v;
   w.order = v.order + first;
   w.team = gw;
-  auto kern = fill_affine_kernel<S, BETA_NONPOS, TW, XCU, DENSE, LEAN>;
+  b->packed_layers = PACK;
+  if (PACK) b->used_pack = true;
+  auto kern = fill_affine_kernel<S, BETA_NONPOS, TW, XCU, DENSE, LEAN, false, PACK>;
   const size_t lds = (S == 2 && TW == 8) ? b->lds_diet8 : b->lds_base + (size_t)TW * b->lds_per_wave;
   if (lds > 64 * 1024)
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -249,6 +258,18 @@ int launch_fill_affine_l(bialign_batch* b, const DeviceBatch& v, int first, int 
     }
     b->last_team = 1;
     return launch_fill_affine_t<S, true, 1, false, true, LEAN>(b, v, first, count, 1);
+  }
+  if constexpr ((S == 1 || S == 2) && !LEAN) {
+    if (b->pack_now()) {  // same launch shapes, packed records
+      if constexpr (S == 2) {
+        if (ts.gw > 1 && ts.tw == 8) return launch_fill_affine_t<S, true, 8, true, false, false, true>(b, v, first, count, ts.gw);
+      }
+      if (ts.gw > 1) return launch_fill_affine_t<S, true, 1, true, false, false, true>(b, v, first, count, ts.gw);
+      if (ts.tw == 8) return launch_fill_affine_t<S, true, 8, false, false, false, true>(b, v, first, count, 1);
+      if (ts.tw >= 4) return launch_fill_affine_t<S, true, 4, false, false, false, true>(b, v, first, count, 1);
+      if (ts.tw >= 2) return launch_fill_affine_t<S, true, 2, false, false, false, true>(b, v, first, count, 1);
+      return launch_fill_affine_t<S, true, 1, false, false, false, true>(b, v, first, count, 1);
+    }
   }
   if constexpr (S == 2) {
     if (ts.gw > 1 && ts.tw == 8) return launch_fill_affine_t<S, true, 8, true, false, LEAN>(b, v, first, count, ts.gw);
@@ -316,6 +337,21 @@ int launch_traceback_affine(const bialign_batch* b, const DeviceBatch& v, int fi
   if (b->lds_trace > 64 * 1024)
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(traceback_affine_kernel<S, true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_trace));
+  if constexpr (S == 1 || S == 2) {
+    if (b->packed_layers) {
+      if (b->lds_trace > 64 * 1024)
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(traceback_affine_kernel<S, true, false, false, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_trace));
+      if (do_trace)
+        hipLaunchKernelGGL((traceback_affine_kernel<S, true, false, false, true>), dim3(blocks), dim3(64), b->lds_trace,
+                           b->eng->stream, w, count);
+      else
+        hipLaunchKernelGGL((traceback_affine_kernel<S, false, false, false, true>), dim3(blocks), dim3(64), 0,
+                           b->eng->stream, w, count);
+      HIP_TRY(hipGetLastError());
+      return BIALIGN_OK;
+    }
+  }
   if (do_trace)
     hipLaunchKernelGGL((traceback_affine_kernel<S, true>), dim3(blocks), dim3(64), b->lds_trace, b->eng->stream, w, count);
   else
@@ -406,6 +442,13 @@ int launch_traceback_linear(const bialign_batch* b, const DeviceBatch& v, int fi
 
 template <int S, int NL>
 int launch_dump(const bialign_batch* b, const DeviceBatch& v, int pid, int32_t* d_out) {
+  if constexpr ((S == 1 || S == 2) && NL == 9) {
+    if (b->packed_layers) {
+      hipLaunchKernelGGL((dump_layers_kernel<S, NL, true>), dim3(256), dim3(256), 0, b->eng->stream, v, pid, d_out);
+      HIP_TRY(hipGetLastError());
+      return BIALIGN_OK;
+    }
+  }
   hipLaunchKernelGGL((dump_layers_kernel<S, NL>), dim3(256), dim3(256), 0, b->eng->stream, v, pid, d_out);
   HIP_TRY(hipGetLastError());
   return BIALIGN_OK;

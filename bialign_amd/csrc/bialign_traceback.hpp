@@ -61,9 +61,11 @@ __device__ __forceinline__ int wave_min16(int v) {  // min over lanes 0..15, val
 //   only row of it a candidate can touch from here, is in the LEAN records) or ends.
 //   WIDE (max_shift beyond the tiled kernels, bialign_wide.hpp): the band half-width is the runtime
 //   value A.wide_s and the layers lie in the reference's own order; S is then a dummy (0).
-template <int S, bool DO_TRACE, bool STRIP = false, bool WIDE = false>
+//   PACK: the sweep stored packed records in interior steps (Pack<S>).
+template <int S, bool DO_TRACE, bool STRIP = false, bool WIDE = false, bool PACK = false>
 __global__ void __launch_bounds__(64) traceback_affine_kernel(const DeviceBatch A, int npairs) {
   static_assert(!WIDE || !STRIP, "no lean traceback on the wide-band path");
+  static_assert(!PACK || (!WIDE && !STRIP), "packed records: full-storage tiled sweeps");
   const int SR = WIDE ? A.wide_s : S;  // band half-width
   const int pid = A.order[blockIdx.x];
   const PairDesc pd = A.pairs[pid];
@@ -86,6 +88,7 @@ __global__ void __launch_bounds__(64) traceback_affine_kernel(const DeviceBatch 
   // layer value (state ss) of lattice point (pi, pj, a, b)
   auto cell = [&](int pi, int pj, int a, int b, int ss) -> int {
     if (WIDE) return lay[pd.layer_off + wide_dword(m, 2 * SR + 1, 9, pi, pj, a, b, ss)];
+    if (PACK) return packed_cell<S>(lay, pd, pi, pj, a, b, ss);
     if (!STRIP) return lay[cell_dword<S, 9>(pd, pi, pj, a, b, ss)];
     const int sp = pi / RR, ilp = pi - sp * RR + 1;
     if (sp >= Qlo)  // inside a re-swept strip: record = step within the strip

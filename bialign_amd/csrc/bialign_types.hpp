@@ -92,6 +92,82 @@ struct Rec {
   }
 };
 
+// ---------------------------------------------------------------------------
+// Packed records (affine sweeps at max_shift 1 and 2, full storage).  In INTERIOR steps -- every lane's
+// lattice points have all four coordinates >= 1 and lie inside the molecule -- each of a lane's ND
+// layer values is either exactly -2^30 at one of six compile-time-known (state, b) positions
+// (can_be_empty<W>) or lies within a few thousand of the lane's first value, so the lane record shrinks
+// from ND dwords to  base + ND unsigned 16-bit offsets  (base = M[(1,1,1,1)] of the lane's first point
+// - 0x8000; offset 0xffff at a can_be_empty position = -2^30): 16 dwords instead of 27 at s=1, 24
+// instead of 45 at s=2.  The sweep verifies the range of every offset it stores; the first one that does
+// not fit raises the device flag and the host repeats the batch with full records.  All other steps
+// (strip changes, the first strip(s), the lattice border) keep full records in a second region of the
+// pair's storage.  Which steps are interior is a function of the record number alone, so readers
+// (ghost feed, tracebacks, dump) find a cell without any index:
+//   record r = Q*P + t,  t = j + 2*il + aa  (Q = strip of the lane, t may reach into the next period)
+//   phase c = r mod P, step-strip Qs = r div P;   interior  <=>  Qs >= Q0  and  LO <= c <= HI
+// ---------------------------------------------------------------------------
+// the six (state, band column) positions whose value can be exactly -2^30 in an interior step (= can_be_empty<W>)
+__host__ __device__ constexpr bool pack_corner(int W, int st, int bb) {
+  return (bb == 0 && (st == 3 || st == 5 || st == 6)) || (bb == W - 1 && (st == 1 || st == 2 || st == 7));
+}
+
+template <int S>
+struct Pack {
+  using G_ = Geo<S>;
+  using R_ = Rec<S, 9>;
+  static constexpr int ND = R_::ND;
+  static constexpr int NCH = (2 + ND + 7) / 8;        // 16-byte chunks of a packed lane record
+  static constexpr int RECDW = NCH * R_::CH;          // same [chunk][slot][4 dwords] shape as full records
+  static constexpr int LO = S + 1 + G_::MAXOFF;       // first phase at which every lane has passed column S
+  static constexpr int Q0 = (S + 2 + G_::RR - 1) / G_::RR;  // first strip whose ghost row is row >= S+1
+  __host__ __device__ static inline int hi(int m) { return m - S; }  // last phase whose points all lie inside the molecule
+  __host__ __device__ static inline bool interior(int qs, int c, int m) { return qs >= Q0 && c >= LO && c <= m - S; }
+  __host__ __device__ static inline int nbs(int P, int m) { return P - (m - S - LO + 1); }  // full records per strip >= Q0
+  // index of the full record of a non-interior step among the pair's full records
+  __host__ __device__ static inline int64_t bidx(int qs, int c, int P, int m) {
+    if (qs < Q0) return (int64_t)qs * P + c;
+    return (int64_t)Q0 * P + (int64_t)(qs - Q0) * nbs(P, m) + (c < LO ? c : c - (m - S + 1) + LO);
+  }
+  // dwords of the pair's full-record region; records 0 .. G-1
+  __host__ __device__ static inline int64_t full_records(int G, int P, int m) {
+    const int nst = (G + P - 1) / P;  // step-strips touched
+    return nst <= Q0 ? (int64_t)nst * P : (int64_t)Q0 * P + (int64_t)(nst - Q0) * nbs(P, m);
+  }
+  // dwords of a pair's storage in packed form: G packed records (those of non-interior steps stay unused), then
+  // its full records
+  __host__ __device__ static inline int64_t pair_dwords(int G, int P, int m) {
+    return (int64_t)G * RECDW + full_records(G, P, m) * R_::RECDW;
+  }
+  // dwords a packed sweep writes (about: idle steps at the very end write nothing in either form)
+  __host__ __device__ static inline int64_t written_dwords(int G, int P, int m) {
+    const int64_t f = full_records(G, P, m);
+    return (G - f) * RECDW + f * R_::RECDW;
+  }
+  // value (state st of band column bb) of a lane slot in a packed record at p
+  __host__ __device__ static inline int decode(const int32_t* p, int slot, int bb, int st, bool corner) {
+    const int h = 2 + bb * 9 + st, dw = h >> 1;
+    const uint32_t word = (uint32_t)p[(dw >> 2) * R_::CH + slot * 4 + (dw & 3)];
+    const uint32_t e = (h & 1) ? word >> 16 : word & 0xffffu;
+    return (corner && e == 0xffffu) ? NEG : p[slot * 4] + (int)e;
+  }
+};
+
+// Layer value (state st) of lattice point (i, j, aa, bb) of a pair swept with packed records.
+template <int S>
+__host__ __device__ inline int packed_cell(const int32_t* layers, const PairDesc& pd, int i, int j, int aa, int bb, int st) {
+  using PK = Pack<S>;
+  constexpr int W = 2 * S + 1, RR = Geo<S>::RR;
+  const int strip = i / RR, il = i - strip * RR + 1;
+  const int t = j + 2 * il + aa, over = t >= pd.P ? 1 : 0;
+  const int slot = (il - 1) * W + aa;
+  const int32_t* base = layers + pd.layer_off;
+  if (PK::interior(strip + over, t - over * pd.P, pd.m))
+    return PK::decode(base + ((int64_t)strip * pd.P + t) * PK::RECDW, slot, bb, st, pack_corner(W, st, bb));
+  return base[(int64_t)pd.G * PK::RECDW + PK::bidx(strip + over, t - over * pd.P, pd.P, pd.m) * Rec<S, 9>::RECDW +
+              Rec<S, 9>::dword(0, slot, bb * 9 + st)];
+}
+
 // dword index of layer value (state st) of lattice point (i, j, aa, bb).
 template <int S, int NL>
 __host__ __device__ inline int64_t cell_dword(const PairDesc& pd, int i, int j, int aa, int bb,

@@ -157,7 +157,8 @@ class Batch:
         check(lib.bialign_batch_get_timing(self._h, ctypes.byref(t)))
         return dict(fill_ms=t.fill_ms, traceback_ms=t.traceback_ms,
                     fill_launches=t.fill_launches, traceback_launches=t.traceback_launches,
-                    waves_per_pair=t.waves_per_pair, cross_cu=bool(t.cross_cu), recovered_runs=t.recovered_runs)
+                    waves_per_pair=t.waves_per_pair, cross_cu=bool(t.cross_cu), recovered_runs=t.recovered_runs,
+                    packed_records=bool(t.packed_records))
 
     def scores(self):
         out = np.empty(self.npairs, dtype=np.int32)

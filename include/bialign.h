@@ -137,7 +137,8 @@ typedef struct bialign_timing {
   int32_t cross_cu;       /* 1 if that team was spread over one-wave workgroups */
   int32_t recovered_runs; /* runs of this batch repeated with in-workgroup teams after a cross-CU team lost
                              co-residency (another tenant on the device); the results are those of the repeat */
-  int32_t reserved;
+  int32_t packed_records; /* 1 if the last run's sweeps stored packed layer records (affine, max_shift 1 or 2: base +
+                             16-bit offsets in interior steps, decoded by the tracebacks; chosen by the engine, exact) */
 } bialign_timing;
 
 int bialign_abi_version(void);
