@@ -213,6 +213,8 @@ def main():
                        "cells_per_gpu": info["cells"], "chunks_per_step": info["nchunks"],
                        "layer_bytes_per_gpu": info["layer_bytes"], "hbm_layer_buffer_bytes": info["hbm_layer_bytes"],
                        "waves_per_pair": timing["waves_per_pair"],
+                       # interior steps store base + 16-bit offsets (lossless, decoded by ghost feed and traceback)
+                       "layer_records": "packed" if timing.get("packed_records") else "full",
                        "sharding": f"rank r owns pairs [r*{args.pairs}, (r+1)*{args.pairs}) of {args.pairs * world}; "
                                    f"no data-path collective, one all_gather of int32 scores",
                        "layer_buffer_placement": placement},

@@ -468,7 +468,7 @@ int bialign_batch_create(bialign_engine* eng, const bialign_params* prm, const b
       const int64_t scratch_dw = (int64_t)(d.m + 2 * (64 / W - 1) + W) * full_rec;  // one strip: m + MAXOFF + 1 records
       d.scratch_off = lean_dw;  // relative to layer_off until the chunk layout is fixed below
       pair_dwords[p] = b->lean_trace ? lean_dw + b->resw_k * scratch_dw : (b->lean ? lean_dw : (int64_t)d.G * full_rec);
-      if (b->pack)  // room for either form: a sweep that meets an unpackable value is repeated with full records
+      if (b->pack && !b->lean)  // room for either form: a sweep that meets an unpackable value is repeated with full records
         pair_dwords[p] = std::max(pair_dwords[p], S == 1 ? Pack<1>::pair_dwords(d.G, d.P, d.m) : Pack<2>::pair_dwords(d.G, d.P, d.m));
     }
   };
@@ -483,9 +483,14 @@ int bialign_batch_create(bialign_engine* eng, const bialign_params* prm, const b
   size_pairs();
   // A pair whose full layers exceed the budget is served from reduced storage instead of failing
   // (memory-lean traceback, ~1.3x the time).
+  if (b->pack && *std::max_element(pair_dwords.begin(), pair_dwords.end()) > budget_dw) {
+    b->pack = false;  // the packed form keeps room for both: full records alone may still fit
+    size_pairs();
+  }
   if (!b->lean && !b->wide &&
       *std::max_element(pair_dwords.begin(), pair_dwords.end()) > budget_dw) {
     b->lean = b->lean_trace = true;
+    b->pack = false;
     pick_resw_k();
   }
   b->order.resize(pr->npairs);

@@ -124,6 +124,17 @@ struct GhostFeed {
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
 
+  // the first NPK pieces only (a packed lane record)
+  template <int NPK>
+  __device__ static __forceinline__ void fetch_pieces(int (&out)[4 * NPK], const v4i* half, int t, int aa) {
+    const v4i* src = half + (t * W + aa) * NP;
+#pragma unroll
+    for (int c = 0; c < NPK; ++c) {
+      const v4i v = src[c];
+      out[4 * c] = v.x; out[4 * c + 1] = v.y; out[4 * c + 2] = v.z; out[4 * c + 3] = v.w;
+    }
+  }
+
   __device__ static __forceinline__ void fetch(int (&out)[R_::ND], const v4i* half, int t, int aa) {
     const v4i* src = half + (t * W + aa) * NP;
 #pragma unroll

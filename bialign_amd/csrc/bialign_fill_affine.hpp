@@ -35,6 +35,10 @@ template <bool V>
 struct BoolTag {
   static constexpr bool value = V;
 };
+template <int V>
+struct IntTag {
+  static constexpr int value = V;
+};
 
 // BETA_NONPOS: gap_opening_cost <= 0 (every practical parameter set).  Then
 // open(h,T) + v[h] <= v[T] + ... lets f_X, f_Y reuse f_M's max3:
@@ -293,23 +297,25 @@ __global__ void __launch_bounds__(64 * TW) fill_affine_kernel(const DeviceBatch 
       prefetch_block(g + GF::BLK, ghalf ^ 1, jj + GF::BLK);
       vm_younger = 0;
     }
-    GF::fetch(ghostM, ring + ghalf * GF::SLOTS, gt, aa);
+    bool ghost_packed = false;
     if (PACK) {  // the ghost row replays record (c + 2(R-1)) of the strip above: packed if that step was interior
       const int c0 = __builtin_amdgcn_readfirstlane(jj), q0 = __builtin_amdgcn_readfirstlane(strip);
       const int ts = c0 + 2 * (R - 1), over = ts >= P ? 1 : 0;
-      if (PK_::interior(q0 * T + w - 1 + over, ts - over * P, m)) {
-        int raw[4 * PK_::NCH];
+      ghost_packed = PK_::interior(q0 * T + w - 1 + over, ts - over * P, m);
+    }
+    if (PACK && ghost_packed) {
+      int raw[4 * PK_::NCH];
+      GF::template fetch_pieces<PK_::NCH>(raw, ring + ghalf * GF::SLOTS, gt, aa);
 #pragma unroll
-        for (int k = 0; k < 4 * PK_::NCH; ++k) raw[k] = ghostM[k < ND ? k : 0];
-#pragma unroll
-        for (int d = 0; d < ND; ++d) {
-          const int h = 2 + d;
-          const unsigned word = (unsigned)raw[h >> 1];
-          const unsigned e = (h & 1) ? word >> 16 : word & 0xffffu;
-          const int v = raw[0] + (int)e;
-          ghostM[d] = pack_corner(W, d % 9, d / 9) ? (e == 0xffffu ? NEG : v) : v;
-        }
+      for (int d = 0; d < ND; ++d) {
+        const int h = 2 + d;
+        const unsigned word = (unsigned)raw[h >> 1];
+        const unsigned e = (h & 1) ? word >> 16 : word & 0xffffu;
+        const int v = raw[0] + (int)e;
+        ghostM[d] = pack_corner(W, d % 9, d / 9) ? (e == 0xffffu ? NEG : v) : v;
       }
+    } else {
+      GF::fetch(ghostM, ring + ghalf * GF::SLOTS, gt, aa);
     }
 
     // ---- 1. exchange reads: what the three source lanes published last step.  Rows of band
@@ -542,9 +548,10 @@ __global__ void __launch_bounds__(64 * TW) fill_affine_kernel(const DeviceBatch 
               for (int x = 0; x < 4; ++x) {
                 const int d = 4 * c + x;  // dword of the lane record
                 const int lo = 2 * d - 2, hi = 2 * d - 1;
+                // low halves of two offsets into one dword: one v_perm_b32
                 dw[x] = d == 0 ? pk_base
-                               : ((lo < ND ? pk_e[PACK && lo < ND ? lo : 0] & 0xffff : 0) |
-                                  (hi < ND ? pk_e[PACK && hi < ND ? hi : 0] << 16 : 0));
+                               : (int)__builtin_amdgcn_perm((unsigned)(hi < ND ? pk_e[PACK && hi < ND ? hi : 0] : 0),
+                                                            (unsigned)(lo < ND ? pk_e[PACK && lo < ND ? lo : 0] : 0), 0x05040100u);
               }
               v4i v;
               v.x = dw[0]; v.y = dw[1]; v.z = dw[2]; v.w = dw[3];
@@ -684,6 +691,8 @@ __global__ void __launch_bounds__(64 * TW) fill_affine_kernel(const DeviceBatch 
   // Interior steps by record number (Pack<S>::interior; lane 0 = ghost row, a = -s, carries the wave's phase):
   // phase c in [LO, m - S] puts every lane inside the molecule columns with all its band points, strip >= Q0
   // puts every lane row at i >= S + 1.  Readers of packed records apply the same rule to find a cell.
+  // (Deciding the kind of a whole run of steps at once -- counted loops instead of a test per step -- costs
+  //  ~40 registers in hipcc's allocation and spills the eight-wave s=2 kernels: measured, not kept.)
   auto all_interior = [&]() __attribute__((always_inline)) {
     const int c0 = __builtin_amdgcn_readfirstlane(jj), q0 = __builtin_amdgcn_readfirstlane(strip);
     return PK_::interior(Qbase + q0 * T + w, c0, m);

@@ -147,9 +147,10 @@ struct Pack {
   // value (state st of band column bb) of a lane slot in a packed record at p
   __host__ __device__ static inline int decode(const int32_t* p, int slot, int bb, int st, bool corner) {
     const int h = 2 + bb * 9 + st, dw = h >> 1;
+    const int base = p[slot * 4];  // both loads issued together: one memory round trip per cell
     const uint32_t word = (uint32_t)p[(dw >> 2) * R_::CH + slot * 4 + (dw & 3)];
     const uint32_t e = (h & 1) ? word >> 16 : word & 0xffffu;
-    return (corner && e == 0xffffu) ? NEG : p[slot * 4] + (int)e;
+    return (corner && e == 0xffffu) ? NEG : base + (int)e;
   }
 };
 
