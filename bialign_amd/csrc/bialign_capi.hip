@@ -474,8 +474,13 @@ int bialign_batch_create(bialign_engine* eng, const bialign_params* prm, const b
   };
   // lean traceback: few pairs -> several strips per round (they re-sweep in parallel), as memory allows
   auto pick_resw_k = [&]() {
-    b->resw_k = (int)std::min<int64_t>(32, std::max<int64_t>(1, 2048 / pr->npairs));
-    if (const char* e = getenv("BIALIGN_RESW_K")) b->resw_k = std::min(32, std::max(1, atoi(e)));  // tests
+    // as many strips per round as keep ~2048 waves busy -- re-sweeps of different strips are independent, so a
+    // single long pair gets up to 256 at once -- but no more scratch than about a quarter of the pair's full
+    // layers (a strip's scratch is 1/NS of them): the mode exists to save memory
+    int ns_max = 1;
+    for (const PairDesc& d : b->pairs) ns_max = std::max(ns_max, d.NS);
+    b->resw_k = (int)std::min<int64_t>(std::min<int64_t>(256, std::max(1, ns_max / 4)), std::max<int64_t>(1, 2048 / pr->npairs));
+    if (const char* e = getenv("BIALIGN_RESW_K")) b->resw_k = std::min(256, std::max(1, atoi(e)));  // tests
     for (size_pairs(); b->resw_k > 1 && *std::max_element(pair_dwords.begin(), pair_dwords.end()) > budget_dw; size_pairs())
       b->resw_k /= 2;
   };
