@@ -468,8 +468,10 @@ int bialign_batch_create(bialign_engine* eng, const bialign_params* prm, const b
       const int64_t scratch_dw = (int64_t)(d.m + 2 * (64 / W - 1) + W) * full_rec;  // one strip: m + MAXOFF + 1 records
       d.scratch_off = lean_dw;  // relative to layer_off until the chunk layout is fixed below
       pair_dwords[p] = b->lean_trace ? lean_dw + b->resw_k * scratch_dw : (b->lean ? lean_dw : (int64_t)d.G * full_rec);
-      if (b->pack && !b->lean)  // room for either form: a sweep that meets an unpackable value is repeated with full records
-        pair_dwords[p] = std::max(pair_dwords[p], S == 1 ? Pack<1>::pair_dwords(d.G, d.P, d.m) : Pack<2>::pair_dwords(d.G, d.P, d.m));
+      if (b->pack && !b->lean) {  // room for either form: a sweep that meets an unpackable value is repeated with full records
+        const int64_t packed = S == 1 ? Pack<1>::pair_dwords(d.G, d.P, d.m) : Pack<2>::pair_dwords(d.G, d.P, d.m);
+        pair_dwords[p] = getenv("BIALIGN_EXP_PACK_SIZING") ? packed : std::max(pair_dwords[p], packed);  // (experiment: no fallback room)
+      }
     }
   };
   // lean traceback: few pairs -> several strips per round (they re-sweep in parallel), as memory allows

@@ -66,9 +66,10 @@ extern "C" {
  * and bialign_batch_get_traces / bialign_batch_dump_layers fail with BIALIGN_E_INVALID. */
 #define BIALIGN_BATCH_SCORE_ONLY 1u
 /* LEAN_TRACE: full results (scores and traces) from the same reduced storage: after the lean sweep
- * the traceback re-sweeps one strip of lattice rows at a time into a small per-pair scratch area
- * and walks through it.  About a tenth of the HBM footprint of the default mode for ~1.3x the time:
- * for pairs whose layers would not fit otherwise. */
+ * the traceback re-sweeps strips of lattice rows into a per-pair scratch area -- as many at a time as
+ * keep the device busy and the HBM budget allows, at most a quarter of the pair's full layers -- and
+ * walks through them.  A twelfth to a third of the HBM footprint of the default mode (hbm_budget_bytes
+ * decides) for ~1.1-1.3x the time: for pairs whose layers would not fit otherwise. */
 #define BIALIGN_BATCH_LEAN_TRACE 2u
 
 typedef struct bialign_engine bialign_engine; /* one per (process, device) */

@@ -152,10 +152,15 @@ def test_single_long_pair_many_strips_per_round():
 
 
 def test_one_pair_of_length_twenty_thousand():
-    """130 GB of layers in the default mode, 7 GB here: same score, same 40 000-column trace."""
+    """124 GB of layers in the default mode; a third of that here with 250 strips re-swept per round (the budget
+    allows it), a twelfth with 32: same score, same 40 000-column trace."""
     pairs = [synth.protein_pair(1700, 20000, 19000)]
     full, lean = same(pairs, dict(synth.PROTEIN_PARAMS))
-    assert lean[3]["hbm_layer_bytes"] * 8 < full[3]["hbm_layer_bytes"]
+    assert lean[3]["hbm_layer_bytes"] * 3 < full[3]["hbm_layer_bytes"]
+    small = run(pairs, dict(synth.PROTEIN_PARAMS), lean_trace=True, hbm_budget_bytes=12 << 30)   # a tight budget: fewer strips per round
+    assert small[3]["hbm_layer_bytes"] <= 12 << 30
+    np.testing.assert_array_equal(small[0], full[0])
+    assert small[1] == full[1] and small[2] == full[2]
     print(f"full: fill {full[4]['fill_ms']:.0f} tb {full[4]['traceback_ms']:.0f} ms, {full[3]['hbm_layer_bytes'] / 2**30:.1f} GiB | "
           f"lean: fill {lean[4]['fill_ms']:.0f} tb {lean[4]['traceback_ms']:.0f} ms, {lean[3]['hbm_layer_bytes'] / 2**30:.1f} GiB")
 
