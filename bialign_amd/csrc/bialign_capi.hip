@@ -276,6 +276,61 @@ int launch_dump_any(const bialign_batch* b, const DeviceBatch& v, int pid, int32
   return fail(BIALIGN_E_UNSUPPORTED, "no dump kernel for affine=%d max_shift=%d", b->affine, b->S);
 }
 
+// Cut the batch into chunks of at most budget_dw dwords of layer storage and lay the pairs of each chunk end to
+// end: as few chunks as the budget allows, of about equal size (an undersized last chunk would leave SIMDs
+// idle); inside a chunk the longest sweeps are launched first.
+int plan_chunks(bialign_batch* b, const std::vector<int64_t>& pair_dwords, int64_t budget_dw) {
+  const int npairs = b->npairs;
+  b->order.resize(npairs);
+  std::iota(b->order.begin(), b->order.end(), 0);
+  b->chunk_begin.assign(1, 0);
+  b->max_chunk_dwords = 0;
+  int64_t total_dw = 0;
+  for (int p = 0; p < npairs; ++p) {
+    if (pair_dwords[p] > budget_dw)
+      return fail(BIALIGN_E_NOMEM, "pair %d needs %lld bytes of layers, budget is %lld", p,
+                  (long long)pair_dwords[p] * 4, (long long)budget_dw * 4);
+    total_dw += pair_dwords[p];
+  }
+  const int64_t want_chunks = (total_dw + budget_dw - 1) / budget_dw;
+  const int64_t target_dw = std::min(budget_dw, (total_dw + want_chunks - 1) / want_chunks);
+  int64_t used = 0;
+  for (int p = 0; p < npairs; ++p) {
+    if (used > 0 && (used + pair_dwords[p] > budget_dw || used >= target_dw)) {
+      b->chunk_begin.push_back(p);
+      used = 0;
+    }
+    b->pairs[p].scratch_off += used - b->pairs[p].layer_off;  // (relative to the pair's start until the first plan)
+    b->pairs[p].layer_off = used;
+    used += pair_dwords[p];
+    b->max_chunk_dwords = std::max(b->max_chunk_dwords, used);
+  }
+  b->chunk_begin.push_back(npairs);
+  for (size_t c = 0; c + 1 < b->chunk_begin.size(); ++c)
+    std::stable_sort(b->order.begin() + b->chunk_begin[c], b->order.begin() + b->chunk_begin[c + 1],
+                     [&](int x, int y) {
+                       return b->wide ? b->pairs[x].n + b->pairs[x].m > b->pairs[y].n + b->pairs[y].m  // levels
+                                      : b->pairs[x].G > b->pairs[y].G;
+                     });
+  return BIALIGN_OK;
+}
+
+// A batch laid out for packed records has to continue with full ones (an offset did not fit): cut it into chunks
+// again, now by the pairs' full-record sizes, within the layer buffer it already holds (a larger one only if a
+// single pair needs it), and hand the new layout to the device.
+int replan_full(bialign_batch* b) {
+  if (!b->packed_sizing) return BIALIGN_OK;
+  b->packed_sizing = false;
+  hipStream_t st = b->eng->stream;
+  HIP_TRY(hipStreamSynchronize(st));
+  const int64_t need = *std::max_element(b->full_dwords.begin(), b->full_dwords.end());
+  if ((int64_t)b->d_layers.n < need + 16) HIP_TRY(b->d_layers.alloc((size_t)need + 16));
+  if (int rc = plan_chunks(b, b->full_dwords, (int64_t)b->d_layers.n - 16)) return rc;
+  HIP_TRY(hipMemcpy(b->d_pairs.p, b->pairs.data(), b->pairs.size() * sizeof(PairDesc), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(b->d_order.p, b->order.data(), b->order.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  return BIALIGN_OK;
+}
+
 int check_device_error(const bialign_batch* b) {
   int32_t err = 0;
   HIP_TRY(hipMemcpy(&err, b->d_err.p, sizeof err, hipMemcpyDeviceToHost));
@@ -468,10 +523,8 @@ int bialign_batch_create(bialign_engine* eng, const bialign_params* prm, const b
       const int64_t scratch_dw = (int64_t)(d.m + 2 * (64 / W - 1) + W) * full_rec;  // one strip: m + MAXOFF + 1 records
       d.scratch_off = lean_dw;  // relative to layer_off until the chunk layout is fixed below
       pair_dwords[p] = b->lean_trace ? lean_dw + b->resw_k * scratch_dw : (b->lean ? lean_dw : (int64_t)d.G * full_rec);
-      if (b->pack && !b->lean) {  // room for either form: a sweep that meets an unpackable value is repeated with full records
-        const int64_t packed = S == 1 ? Pack<1>::pair_dwords(d.G, d.P, d.m) : Pack<2>::pair_dwords(d.G, d.P, d.m);
-        pair_dwords[p] = getenv("BIALIGN_EXP_PACK_SIZING") ? packed : std::max(pair_dwords[p], packed);  // (experiment: no fallback room)
-      }
+      if (b->pack && !b->lean)  // (a sweep that meets an unpackable value is repeated with full records: replan_full())
+        pair_dwords[p] = S == 1 ? Pack<1>::pair_dwords(d.G, d.P, d.m) : Pack<2>::pair_dwords(d.G, d.P, d.m);
     }
   };
   // lean traceback: few pairs -> several strips per round (they re-sweep in parallel), as memory allows
@@ -490,9 +543,14 @@ int bialign_batch_create(bialign_engine* eng, const bialign_params* prm, const b
   size_pairs();
   // A pair whose full layers exceed the budget is served from reduced storage instead of failing
   // (memory-lean traceback, ~1.3x the time).
-  if (b->pack && *std::max_element(pair_dwords.begin(), pair_dwords.end()) > budget_dw) {
-    b->pack = false;  // the packed form keeps room for both: full records alone may still fit
-    size_pairs();
+  if (b->pack) {  // the fallback to full records must be possible within the same budget
+    int64_t full_max = 0;
+    for (const PairDesc& d : b->pairs)
+      full_max = std::max(full_max, (int64_t)d.G * (S == 1 ? Rec<1, 9>::RECDW : Rec<2, 9>::RECDW));
+    if (std::max(full_max, *std::max_element(pair_dwords.begin(), pair_dwords.end())) > budget_dw) {
+      b->pack = false;
+      size_pairs();
+    }
   }
   if (!b->lean && !b->wide &&
       *std::max_element(pair_dwords.begin(), pair_dwords.end()) > budget_dw) {
@@ -500,38 +558,14 @@ int bialign_batch_create(bialign_engine* eng, const bialign_params* prm, const b
     b->pack = false;
     pick_resw_k();
   }
-  b->order.resize(pr->npairs);
-  std::iota(b->order.begin(), b->order.end(), 0);
-  b->chunk_begin.push_back(0);
-  // as few chunks as the budget allows, of about equal size (an undersized last chunk
-  // would leave SIMDs idle): fill each chunk up to total / nchunks, never beyond the budget
-  int64_t total_dw = 0;
+  b->full_dwords.resize(pr->npairs);
   for (int p = 0; p < pr->npairs; ++p) {
-    if (pair_dwords[p] > budget_dw)
-      return fail(BIALIGN_E_NOMEM, "pair %d needs %lld bytes of layers, budget is %lld", p,
-                  (long long)pair_dwords[p] * 4, (long long)budget);
-    total_dw += pair_dwords[p];
+    int slp = (64 / W - 1) * W;  // as in size_pairs
+    if ((slp + 7) / 8 * 8 - slp <= BIALIGN_PADMAX) slp = (slp + 7) / 8 * 8;
+    b->full_dwords[p] = b->wide ? pair_dwords[p] : (int64_t)b->pairs[p].G * ((int64_t)((b->NL * W) / 4) * slp * 4 + 64 * ((b->NL * W) % 4));
   }
-  const int64_t want_chunks = (total_dw + budget_dw - 1) / budget_dw;
-  const int64_t target_dw = std::min(budget_dw, (total_dw + want_chunks - 1) / want_chunks);
-  int64_t used = 0;
-  for (int p = 0; p < pr->npairs; ++p) {
-    if (used > 0 && (used + pair_dwords[p] > budget_dw || used >= target_dw)) {
-      b->chunk_begin.push_back(p);
-      used = 0;
-    }
-    b->pairs[p].layer_off = used;
-    b->pairs[p].scratch_off += used;
-    used += pair_dwords[p];
-    b->max_chunk_dwords = std::max(b->max_chunk_dwords, used);
-  }
-  b->chunk_begin.push_back(pr->npairs);
-  for (size_t c = 0; c + 1 < b->chunk_begin.size(); ++c)
-    std::stable_sort(b->order.begin() + b->chunk_begin[c], b->order.begin() + b->chunk_begin[c + 1],
-                     [&](int x, int y) {
-                       return b->wide ? b->pairs[x].n + b->pairs[x].m > b->pairs[y].n + b->pairs[y].m  // levels
-                                      : b->pairs[x].G > b->pairs[y].G;
-                     });
+  b->packed_sizing = b->pack && !b->lean;
+  if (int rc = plan_chunks(b.get(), pair_dwords, budget_dw)) return rc;
 
   // ---- upload (own stream: a batch can be prepared while another one sweeps)
   hipStream_t st = eng->copy_stream;
@@ -746,6 +780,7 @@ int bialign_batch_wait(bialign_batch* b) {
       if (!b->used_pack || b->pack_failed)
         return fail(BIALIGN_E_DEVICE, "fill kernel: device error flag %d", err);
       b->pack_failed = again = true;
+      if (int rc = replan_full(b)) return rc;
     }
     if (!again) return fail(BIALIGN_E_DEVICE, "fill kernel: device error flag %d", err);
     ++b->recovered;
@@ -818,7 +853,11 @@ int bialign_batch_dump_layers(bialign_batch* b, int32_t pair, int32_t* out) {
     HIP_TRY(hipMemcpy(&err, b->d_err.p, sizeof err, hipMemcpyDeviceToHost));
     if (err) {
       if (err & 1) b->no_xcu = true;
-      if (err & 2) b->pack_failed = true;
+      if (err & 2) {
+        b->pack_failed = true;
+        if (int rc2 = replan_full(b)) return rc2;
+        v = b->view();  // (the layer buffer may have been replaced)
+      }
       ++b->recovered;
       HIP_TRY(hipMemsetAsync(b->d_err.p, 0, sizeof(int32_t), st));
       rc = launch_fill(b, v, pos, 1);

@@ -122,6 +122,8 @@ struct bialign_batch {
   bool used_pack = false;       // a fill launch of the pending / last run stored packed records
   bool packed_layers = false;   // ... and so did the launch whose layers are in the buffer now
   bool pack_now() const { return pack && !pack_failed; }
+  bool packed_sizing = false;          // chunks and pair offsets were planned with the packed sizes
+  std::vector<int64_t> full_dwords;    // per pair: dwords of its full-record form (for the fallback's re-plan)
   DevBuf<uint8_t> d_seq_a, d_cls_a, d_seq_b, d_cls_b, d_trace;
   DevBuf<int32_t> d_mu2;  // dense-mu2 mode: all pairs' n x m tables
   bool dense = false;
