@@ -294,29 +294,46 @@ __global__ void __launch_bounds__(64 * TW) fill_affine_kernel(const DeviceBatch 
       // the DMAs just retired were issued at step g - BLK ahead of that step's stores, and vmcnt retires in
       // order: the stores of all steps before g - BLK are acknowledged
       if ((XCU || TW > 1) && L == 0) prog_put(g - GF::BLK);
+      if (PACK) {
+        // The block that has just landed holds, per (step t, band row a), the ghost row's source as it lies in
+        // HBM: a packed lane record if that step of the strip above was interior (record phase c + 2(R-1)), else
+        // a full one.  Lane t*W + a unpacks its entry in place, once per block -- the ghost lanes then read
+        // plain layer values every step, and only BLK*W lanes of one step in BLK pay for the decode.
+        const int c0 = __builtin_amdgcn_readfirstlane(jj), q0 = __builtin_amdgcn_readfirstlane(strip);
+        if (L < GF::BLK * W) {
+          const int t = L / W, ai = L - t * W;
+          int ph = c0 + t, qst = q0 * T + w;  // lane 0's phase and strip at step g + t
+          if (ph >= P) { ph -= P; qst += T; }
+          const int ts = ph + 2 * (R - 1), over = ts >= P ? 1 : 0;
+          if (PK_::interior(qst - 1 + over, ts - over * P, m)) {
+            v4i* pc = ring + ghalf * GF::SLOTS + (t * W + ai) * GF::NP;
+            int raw[4 * PK_::NCH], dec[4 * GF::NP];
+#pragma unroll
+            for (int c = 0; c < PK_::NCH; ++c) {
+              const v4i v = pc[c];
+              raw[4 * c] = v.x; raw[4 * c + 1] = v.y; raw[4 * c + 2] = v.z; raw[4 * c + 3] = v.w;
+            }
+#pragma unroll
+            for (int d = 0; d < 4 * GF::NP; ++d) {
+              const int h = 2 + d;
+              const unsigned word = (unsigned)raw[d < ND ? h >> 1 : 0];
+              const unsigned e = (h & 1) ? word >> 16 : word & 0xffffu;
+              const int v = raw[0] + (int)e;
+              dec[d] = d >= ND ? 0 : (pack_corner(W, d % 9, d / 9) ? (e == 0xffffu ? NEG : v) : v);
+            }
+#pragma unroll
+            for (int c = 0; c < GF::NP; ++c) {
+              v4i v;
+              v.x = dec[4 * c]; v.y = dec[4 * c + 1]; v.z = dec[4 * c + 2]; v.w = dec[4 * c + 3];
+              pc[c] = v;
+            }
+          }
+        }
+      }
       prefetch_block(g + GF::BLK, ghalf ^ 1, jj + GF::BLK);
       vm_younger = 0;
     }
-    bool ghost_packed = false;
-    if (PACK) {  // the ghost row replays record (c + 2(R-1)) of the strip above: packed if that step was interior
-      const int c0 = __builtin_amdgcn_readfirstlane(jj), q0 = __builtin_amdgcn_readfirstlane(strip);
-      const int ts = c0 + 2 * (R - 1), over = ts >= P ? 1 : 0;
-      ghost_packed = PK_::interior(q0 * T + w - 1 + over, ts - over * P, m);
-    }
-    if (PACK && ghost_packed) {
-      int raw[4 * PK_::NCH];
-      GF::template fetch_pieces<PK_::NCH>(raw, ring + ghalf * GF::SLOTS, gt, aa);
-#pragma unroll
-      for (int d = 0; d < ND; ++d) {
-        const int h = 2 + d;
-        const unsigned word = (unsigned)raw[h >> 1];
-        const unsigned e = (h & 1) ? word >> 16 : word & 0xffffu;
-        const int v = raw[0] + (int)e;
-        ghostM[d] = pack_corner(W, d % 9, d / 9) ? (e == 0xffffu ? NEG : v) : v;
-      }
-    } else {
-      GF::fetch(ghostM, ring + ghalf * GF::SLOTS, gt, aa);
-    }
+    GF::fetch(ghostM, ring + ghalf * GF::SLOTS, gt, aa);
 
     // ---- 1. exchange reads: what the three source lanes published last step.  Rows of band
     //         column r are first needed by point r-1, so they are fetched two points ahead

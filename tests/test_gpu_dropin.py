@@ -238,13 +238,13 @@ def test_properties_long_single_pair():
     _property_check([synth.rna_pair(78, 3000, 3500)], dict(synth.RNA_PARAMS, max_shift=2))
 
 
-def _full_config_check(pairs, params, sample_every, expect_chunks_over):
+def _full_config_check(pairs, params, sample_every, expect_chunks_over, hbm_budget_bytes=0):
     from bialign_amd.batch import encode_pairs
     from bialign_amd.engine import Batch, default_engine
     from bialign_amd.verify import rescore_trace
     model, mols_a, mols_b = encode_pairs(pairs, params)
     b = Batch(default_engine(), mols_a, mols_b, model.s1, model.s2, params["gap_opening_cost"],
-              params["gap_cost"], params["shift_cost"], params["max_shift"])
+              params["gap_cost"], params["shift_cost"], params["max_shift"], hbm_budget_bytes=hbm_budget_bytes)
     assert b.info["nchunks"] > expect_chunks_over          # does not fit HBM at once: chunked
     b.run()
     scores = b.scores()
@@ -263,16 +263,20 @@ def _full_config_check(pairs, params, sample_every, expect_chunks_over):
 
 def test_full_config4():
     """BASELINE config 4 at full size: 256 RNA pairs, len 2000, dot-bracket structures, max_shift=2
-    (921 GB of layers -> several HBM-budgeted chunks)."""
-    info, _ = _full_config_check(synth.rna_batch(256, 2000), dict(synth.RNA_PARAMS, max_shift=2), 8, 2)
+    (921 GB of int32 layers; 2 HBM-budgeted chunks with packed records, 4 without)."""
+    info, _ = _full_config_check(synth.rna_batch(256, 2000), dict(synth.RNA_PARAMS, max_shift=2), 8, 1)
     assert info["cells"] == 256 * 9999 * 9999
 
 
 def test_full_config5_one_gpu_share():
-    """BASELINE config 5, one rank's share (1024 of the 8192 protein pairs, len 1024): 348 GB of
-    layers in two chunks; rank r of 8 would use seeds 1000 + r*1024 + p."""
-    info, scores = _full_config_check(synth.protein_batch(1024, 1024), dict(synth.PROTEIN_PARAMS), 16, 1)
+    """BASELINE config 5, one rank's share (1024 of the 8192 protein pairs, len 1024): 348 GB of int32
+    layers -- one launch with packed records (233 GB), chunked under a 150 GB budget; rank r of 8 would
+    use seeds 1000 + r*1024 + p."""
+    pairs = synth.protein_batch(1024, 1024)
+    info, scores = _full_config_check(pairs, dict(synth.PROTEIN_PARAMS), 16, 0)
     assert info["cells"] == 1024 * 3073 * 3073
+    info2, scores2 = _full_config_check(pairs, dict(synth.PROTEIN_PARAMS), 64, 1, hbm_budget_bytes=150 * 10 ** 9)
+    np.testing.assert_array_equal(scores, scores2)
 
 
 def test_long_molecules_large_lds():
