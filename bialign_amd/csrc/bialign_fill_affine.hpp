@@ -80,6 +80,10 @@ template <int S, bool BETA_NONPOS, int TW, bool XCU, bool DENSE = false, bool LE
 __global__ void __launch_bounds__(64 * TW) fill_affine_kernel(const DeviceBatch A) {
   static_assert(!PACK || (!LEAN && !RESW && S >= 1), "packed records: full-storage sweeps with a band");
   using PK_ = Pack<S>;
+  // Ghost rows of packed records: unpacked once per block by BLK*W lanes (s=1: 24 lanes every 8 steps, -4 % fill
+  // time) or by the ghost lanes' wave in every step (s=2: blocks of 4 or 2 steps, the in-place rewrite at the block
+  // boundary costs more latency than it saves issue slots: 168 vs 172 ms on config 4).
+  constexpr bool PK_COOP = S == 1;
   static_assert(!XCU || TW == 1 || TW == 8, "cross-CU teams are built from one-wave or eight-wave workgroups");
   // DIET (eight waves of the s=2 kernel in one workgroup = two per SIMD on a whole CU): their arrays fit
   // 160 KB of LDS only with half-length ghost blocks and molecule A's codes left in global memory (they
@@ -294,7 +298,7 @@ __global__ void __launch_bounds__(64 * TW) fill_affine_kernel(const DeviceBatch 
       // the DMAs just retired were issued at step g - BLK ahead of that step's stores, and vmcnt retires in
       // order: the stores of all steps before g - BLK are acknowledged
       if ((XCU || TW > 1) && L == 0) prog_put(g - GF::BLK);
-      if (PACK) {
+      if (PACK && PK_COOP) {
         // The block that has just landed holds, per (step t, band row a), the ghost row's source as it lies in
         // HBM: a packed lane record if that step of the strip above was interior (record phase c + 2(R-1)), else
         // a full one.  Lane t*W + a unpacks its entry in place, once per block -- the ghost lanes then read
@@ -333,7 +337,26 @@ __global__ void __launch_bounds__(64 * TW) fill_affine_kernel(const DeviceBatch 
       prefetch_block(g + GF::BLK, ghalf ^ 1, jj + GF::BLK);
       vm_younger = 0;
     }
-    GF::fetch(ghostM, ring + ghalf * GF::SLOTS, gt, aa);
+    bool ghost_packed = false;
+    if (PACK && !PK_COOP) {  // per step: is the ghost row's source record (phase c + 2(R-1) of the strip above) a packed one?
+      const int c0 = __builtin_amdgcn_readfirstlane(jj), q0 = __builtin_amdgcn_readfirstlane(strip);
+      const int ts = c0 + 2 * (R - 1), over = ts >= P ? 1 : 0;
+      ghost_packed = PK_::interior(q0 * T + w - 1 + over, ts - over * P, m);
+    }
+    if (PACK && !PK_COOP && ghost_packed) {
+      int raw[4 * PK_::NCH];
+      GF::template fetch_pieces<PK_::NCH>(raw, ring + ghalf * GF::SLOTS, gt, aa);
+#pragma unroll
+      for (int d = 0; d < ND; ++d) {
+        const int h = 2 + d;
+        const unsigned word = (unsigned)raw[h >> 1];
+        const unsigned e = (h & 1) ? word >> 16 : word & 0xffffu;
+        const int v = raw[0] + (int)e;
+        ghostM[d] = pack_corner(W, d % 9, d / 9) ? (e == 0xffffu ? NEG : v) : v;
+      }
+    } else {
+      GF::fetch(ghostM, ring + ghalf * GF::SLOTS, gt, aa);
+    }
 
     // ---- 1. exchange reads: what the three source lanes published last step.  Rows of band
     //         column r are first needed by point r-1, so they are fetched two points ahead
