@@ -166,6 +166,19 @@ int64_t cells_of(int n, int m, int s) {
   return K(n) * K(m);
 }
 
+// Pack<S> geometry for a runtime max_shift (packed records exist for max_shift 1..3)
+struct PackInfo {
+  int lo;
+  int64_t full_recdw;
+  int64_t (*pair_dwords)(int, int, int);
+  int64_t (*written_dwords)(int, int, int);
+};
+template <int S>
+PackInfo pack_info_of() {
+  return PackInfo{Pack<S>::LO, Rec<S, 9>::RECDW, &Pack<S>::pair_dwords, &Pack<S>::written_dwords};
+}
+PackInfo pack_info(int S) { return S == 1 ? pack_info_of<1>() : (S == 2 ? pack_info_of<2>() : pack_info_of<3>()); }
+
 // diet: the eight-wave form of the s=2 affine kernel (fill_affine_kernel, DIET): half-length ghost blocks,
 // molecule A's codes not staged
 size_t lds_need(int S, int NL, int team, int k1, int k2, int n, int m, bool dense = false, bool diet = false) {
@@ -488,13 +501,14 @@ int bialign_batch_create(bialign_engine* eng, const bialign_params* prm, const b
   {
     const char* e = getenv("BIALIGN_PACK");  // "0" never, "1" wherever the layout allows (tests), unset: when it pays
     const bool force = e && e[0] == '1';
-    bool ok = b->affine && (S == 1 || S == 2) && !b->dense && !b->lean && prm->gap_opening_cost <= 0 && !(e && e[0] == '0') &&
+    const PackInfo pki = pack_info(S);
+    bool ok = b->affine && S >= 1 && S <= BIALIGN_MAX_SHIFT_PACKED && !b->lean && prm->gap_opening_cost <= 0 && !(e && e[0] == '0') &&
               (force || colmax < 8192);  // offsets span a few column scores (measured: up to 2.5): beyond this they will not fit
     for (int p = 0; ok && p < pr->npairs; ++p) {
       const PairDesc& d = b->pairs[p];
-      const int interior = d.m - S - (S == 1 ? Pack<1>::LO : Pack<2>::LO) + 1;  // phases LO .. m - S per strip
-      const int64_t packed_dw = S == 1 ? Pack<1>::written_dwords(d.G, d.P, d.m) : Pack<2>::written_dwords(d.G, d.P, d.m);
-      const int64_t full_dw = (int64_t)d.G * (S == 1 ? Rec<1, 9>::RECDW : Rec<2, 9>::RECDW);
+      const int interior = d.m - S - pki.lo + 1;  // phases LO .. m - S per strip
+      const int64_t packed_dw = pki.written_dwords(d.G, d.P, d.m);
+      const int64_t full_dw = (int64_t)d.G * pki.full_recdw;
       // unless forced (tests): only where it saves a fifth of the bytes written (long enough columns, more than a strip or two)
       ok = interior >= 1 && (force || packed_dw * 5 <= full_dw * 4);
     }
@@ -524,7 +538,7 @@ int bialign_batch_create(bialign_engine* eng, const bialign_params* prm, const b
       d.scratch_off = lean_dw;  // relative to layer_off until the chunk layout is fixed below
       pair_dwords[p] = b->lean_trace ? lean_dw + b->resw_k * scratch_dw : (b->lean ? lean_dw : (int64_t)d.G * full_rec);
       if (b->pack && !b->lean)  // (a sweep that meets an unpackable value is repeated with full records: replan_full())
-        pair_dwords[p] = S == 1 ? Pack<1>::pair_dwords(d.G, d.P, d.m) : Pack<2>::pair_dwords(d.G, d.P, d.m);
+        pair_dwords[p] = pack_info(S).pair_dwords(d.G, d.P, d.m);
     }
   };
   // lean traceback: few pairs -> several strips per round (they re-sweep in parallel), as memory allows
@@ -546,7 +560,7 @@ int bialign_batch_create(bialign_engine* eng, const bialign_params* prm, const b
   if (b->pack) {  // the fallback to full records must be possible within the same budget
     int64_t full_max = 0;
     for (const PairDesc& d : b->pairs)
-      full_max = std::max(full_max, (int64_t)d.G * (S == 1 ? Rec<1, 9>::RECDW : Rec<2, 9>::RECDW));
+      full_max = std::max(full_max, (int64_t)d.G * pack_info(S).full_recdw);
     if (std::max(full_max, *std::max_element(pair_dwords.begin(), pair_dwords.end())) > budget_dw) {
       b->pack = false;
       size_pairs();

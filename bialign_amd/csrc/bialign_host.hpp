@@ -19,6 +19,8 @@
 
 #include "../../include/bialign.h"
 
+#define BIALIGN_MAX_SHIFT_PACKED 3  // packed layer records (Pack<S>) are instantiated for max_shift 1..3
+
 namespace bialign {
 
 int fail(int code, const char* fmt, ...);  // records the message bialign_last_error() returns
@@ -255,19 +257,28 @@ int launch_fill_affine_l(bialign_batch* b, const DeviceBatch& v, int first, int 
                                   xcu_ok ? xcu_resident_blocks<S, LEAN, 8>(b) : 0);
   b->last_team = ts.waves() * (ts.gw > 1 ? -1 : 1);
   if (b->dense) {
+    if constexpr (S >= 1 && S <= BIALIGN_MAX_SHIFT_PACKED && !LEAN) {
+      if (b->pack_now()) {
+        if (ts.tw >= 2) return launch_fill_affine_t<S, true, 2, false, true, false, true>(b, v, first, count, 1);
+        b->last_team = 1;
+        return launch_fill_affine_t<S, true, 1, false, true, false, true>(b, v, first, count, 1);
+      }
+    }
     if constexpr (S <= 3) {
       if (ts.tw >= 2) return launch_fill_affine_t<S, true, 2, false, true, LEAN>(b, v, first, count, 1);
     }
     b->last_team = 1;
     return launch_fill_affine_t<S, true, 1, false, true, LEAN>(b, v, first, count, 1);
   }
-  if constexpr ((S == 1 || S == 2) && !LEAN) {
+  if constexpr (S >= 1 && S <= BIALIGN_MAX_SHIFT_PACKED && !LEAN) {
     if (b->pack_now()) {  // same launch shapes, packed records
       if constexpr (S == 2) {
         if (ts.gw > 1 && ts.tw == 8) return launch_fill_affine_t<S, true, 8, true, false, false, true>(b, v, first, count, ts.gw);
       }
       if (ts.gw > 1) return launch_fill_affine_t<S, true, 1, true, false, false, true>(b, v, first, count, ts.gw);
-      if (ts.tw == 8) return launch_fill_affine_t<S, true, 8, false, false, false, true>(b, v, first, count, 1);
+      if constexpr (S <= 2) {
+        if (ts.tw == 8) return launch_fill_affine_t<S, true, 8, false, false, false, true>(b, v, first, count, 1);
+      }
       if (ts.tw >= 4) return launch_fill_affine_t<S, true, 4, false, false, false, true>(b, v, first, count, 1);
       if (ts.tw >= 2) return launch_fill_affine_t<S, true, 2, false, false, false, true>(b, v, first, count, 1);
       return launch_fill_affine_t<S, true, 1, false, false, false, true>(b, v, first, count, 1);
@@ -339,7 +350,7 @@ int launch_traceback_affine(const bialign_batch* b, const DeviceBatch& v, int fi
   if (b->lds_trace > 64 * 1024)
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(traceback_affine_kernel<S, true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_trace));
-  if constexpr (S == 1 || S == 2) {
+  if constexpr (S >= 1 && S <= BIALIGN_MAX_SHIFT_PACKED) {
     if (b->packed_layers) {
       if (b->lds_trace > 64 * 1024)
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(traceback_affine_kernel<S, true, false, false, true>),
@@ -444,7 +455,7 @@ int launch_traceback_linear(const bialign_batch* b, const DeviceBatch& v, int fi
 
 template <int S, int NL>
 int launch_dump(const bialign_batch* b, const DeviceBatch& v, int pid, int32_t* d_out) {
-  if constexpr ((S == 1 || S == 2) && NL == 9) {
+  if constexpr (S >= 1 && S <= BIALIGN_MAX_SHIFT_PACKED && NL == 9) {
     if (b->packed_layers) {
       hipLaunchKernelGGL((dump_layers_kernel<S, NL, true>), dim3(256), dim3(256), 0, b->eng->stream, v, pid, d_out);
       HIP_TRY(hipGetLastError());

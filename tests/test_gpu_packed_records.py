@@ -1,4 +1,4 @@
-"""Packed layer records (affine sweeps at max_shift 1 and 2): interior steps store base + 16-bit
+"""Packed layer records (affine sweeps at max_shift 1, 2 and 3): interior steps store base + 16-bit
 offsets instead of int32 values, the other steps full records; ghost feed, tracebacks and the dump
 decode.  Lossless by construction -- and checked here against the oracle cell by cell, against the
 golden vectors, with every team shape, and on inputs whose offsets do NOT fit (the sweep notices
@@ -41,7 +41,7 @@ def check(pair, params, expect_packed=True):
 
 
 @pytest.mark.parametrize("n,m,s,seed", [(150, 160, 1, 1), (70, 300, 1, 2), (300, 170, 1, 3), (400, 400, 1, 10),
-                                         (64, 140, 2, 6), (130, 131, 2, 7), (250, 120, 2, 9)])
+                                         (64, 140, 2, 6), (130, 131, 2, 7), (250, 120, 2, 9), (90, 150, 3, 11), (40, 200, 3, 12)])
 def test_default_policy_full_layers(n, m, s, seed):
     """Shapes the engine packs by itself (a quarter of the bytes saved)."""
     check(synth.protein_pair(4000 + seed, n, m), dict(synth.PROTEIN_PARAMS, max_shift=s))
@@ -61,7 +61,7 @@ def test_forced_on_short_pairs(n, m, s, seed, monkeypatch):
 
 @pytest.mark.parametrize("team,n,m,s", [("2", 300, 320, 1), ("4", 170, 400, 1), ("8", 330, 650, 1), ("x3", 130, 300, 1),
                                         ("x8", 330, 650, 1), ("4", 100, 300, 2), ("8", 200, 470, 2), ("x7", 200, 400, 2),
-                                        ("h2", 360, 810, 2)])
+                                        ("h2", 360, 810, 2), ("4", 80, 300, 3), ("x4", 90, 400, 3)])
 def test_team_shapes(team, n, m, s, monkeypatch):
     monkeypatch.setenv("BIALIGN_TEAM", team)
     got = check(synth.protein_pair(4200 + n, n, m), dict(synth.PROTEIN_PARAMS, max_shift=s))
@@ -76,6 +76,34 @@ def test_rna_and_golden_cases():
         check_against_golden(rec)   # whatever form the policy picks for them
 
 
+@pytest.mark.parametrize("s", [1, 2, 3])
+def test_dense_mu2_packed(s):
+    """DENSE mu2 (per-pair int32 tables, the predicted-structure RNA form) with packed records: full layers vs oracle."""
+    from oracle import oracle
+    from bialign_amd.batch import make_batch
+    from bialign_amd.engine import trace_codes_to_columns
+    rng = np.random.default_rng(50 + s)
+    shapes = [(150, 170), (60, 220)]
+    pairs = [synth.rna_pair(4700 + t, n, m) for t, (n, m) in enumerate(shapes)]
+    tabs = [rng.integers(0, 1200, size=(n, m)).astype(np.int32) for n, m in shapes]
+    params = dict(synth.RNA_PARAMS, max_shift=s)
+    b = make_batch(pairs, params, mu2_dense=tabs)
+    b.run()
+    assert b.timing()["packed_records"]
+    scores = b.scores()
+    traces, ok = b.traces()
+    for t, (pair, (n, m)) in enumerate(zip(pairs, shapes)):
+        mu1, _ = oracle.mu_tables(*pair, params)
+        mu2 = np.zeros((n + 1, m + 1), dtype=np.int32)
+        mu2[1:, 1:] = tabs[t]
+        ref = oracle.solve_tables(n, m, params, mu1, mu2)
+        assert int(scores[t]) == ref["score"]
+        assert trace_codes_to_columns(traces[t]) == oracle.trace_to_lists(ref["trace"])
+        for g, e in zip(oracle.band_values(b.dump_layers(t), n, m, s), oracle.band_values(ref["layers"], n, m, s)):
+            np.testing.assert_array_equal(g, e)
+    b.close()
+
+
 def test_off_switch_and_equality(monkeypatch):
     pair, params = synth.protein_pair(4400, 180, 200), dict(synth.PROTEIN_PARAMS)
     a = solve(pair, params)
@@ -87,13 +115,13 @@ def test_off_switch_and_equality(monkeypatch):
 
 
 def test_not_packed_where_it_does_not_apply():
-    for params in (dict(synth.PROTEIN_PARAMS, max_shift=3), dict(synth.PROTEIN_PARAMS, max_shift=0),
+    for params in (dict(synth.PROTEIN_PARAMS, max_shift=4), dict(synth.PROTEIN_PARAMS, max_shift=0),
                    dict(synth.PROTEIN_PARAMS, gap_opening_cost=40),                                   # beta > 0
                    dict(synth.PROTEIN_PARAMS, gap_opening_cost=0, gap_cost=-200, shift_cost=-250)):   # one layer
         check(synth.protein_pair(4500, 150, 160), params, expect_packed=False)
 
 
-@pytest.mark.parametrize("s", [1, 2])
+@pytest.mark.parametrize("s", [1, 2, 3])
 def test_offsets_that_do_not_fit_fall_back(s, monkeypatch):
     """Scores so spread out that neighbouring states differ by more than 16 bits hold: the sweep flags it,
     the run is repeated with full records (once), results equal the oracle, the batch stays unpacked."""
