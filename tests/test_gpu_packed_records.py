@@ -156,6 +156,35 @@ def test_offsets_that_do_not_fit_fall_back(s, monkeypatch):
     assert first >= 1, "these scores were meant to overflow the 16-bit offsets"
 
 
+def test_fallback_replans_a_chunked_batch(monkeypatch):
+    """Eight pairs in three packed chunks (tight budget), offsets overflow: the batch is cut into chunks again by the pairs'
+    full-record sizes inside the buffer it holds, repeated once, and equals the oracle."""
+    from oracle import oracle
+    from bialign_amd.batch import make_batch
+    from bialign_amd.engine import trace_codes_to_columns
+    monkeypatch.setenv("BIALIGN_PACK", "1")
+    params = dict(synth.PROTEIN_PARAMS, simmatrix=None, sequence_match_similarity=5000, sequence_mismatch_similarity=-5000,
+                  structure_weight=100, gap_opening_cost=-5000, gap_cost=-5000, shift_cost=-5000)
+    pairs = [synth.protein_pair(4800 + t, 120 + 9 * t, 170 - 3 * t) for t in range(8)]
+    probe = make_batch(pairs, params)
+    one_chunk = probe.info["hbm_layer_bytes"]
+    probe.close()
+    b = make_batch(pairs, params, hbm_budget_bytes=int(one_chunk * 0.4))
+    chunks_before = b.info["nchunks"]
+    assert chunks_before >= 3
+    b.run()
+    t = b.timing()
+    assert t["recovered_runs"] == 1 and not t["packed_records"]
+    scores = b.scores()
+    traces, ok = b.traces()
+    b.close()
+    for k, pair in enumerate(pairs):
+        ref = oracle.solve(*pair, params)
+        assert int(scores[k]) == ref["score"]
+        assert trace_codes_to_columns(traces[k]) == oracle.trace_to_lists(ref["trace"])
+        assert bool(ok[k]) == ref["complete"]
+
+
 def test_batch_of_1024_len_512_properties():
     """BASELINE configs[1] at full size through the packed path: every trace re-scores to its score."""
     from test_gpu_dropin import _property_check
