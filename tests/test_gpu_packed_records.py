@@ -83,7 +83,7 @@ def test_dense_mu2_packed(s):
     from bialign_amd.batch import make_batch
     from bialign_amd.engine import trace_codes_to_columns
     rng = np.random.default_rng(50 + s)
-    shapes = [(150, 170), (60, 220)]
+    shapes = [(150, 170), (170, 220)]
     pairs = [synth.rna_pair(4700 + t, n, m) for t, (n, m) in enumerate(shapes)]
     tabs = [rng.integers(0, 1200, size=(n, m)).astype(np.int32) for n, m in shapes]
     params = dict(synth.RNA_PARAMS, max_shift=s)
