@@ -639,7 +639,7 @@ void bialign_batch_destroy(bialign_batch* b) {
   if (!b) return;
   (void)hipSetDevice(b->eng->device);
   bialign_engine* eng = b->eng;
-  if (b->pending) (void)hipEventSynchronize(b->evs.back());  // its kernels still use the buffers freed below
+  if (b->pending) (void)hipStreamSynchronize(b->eng->stream);  // its kernels still use the buffers freed below
   if (b->d_layers.p && !eng->closing) {  // keep the buffer for the next batch: a free slot, else in place of a smaller one
     (void)hipStreamSynchronize(eng->stream);
     DevBuf<int32_t>* slot = !eng->layer_cache.p ? &eng->layer_cache : (!eng->layer_cache2.p ? &eng->layer_cache2 : nullptr);
@@ -768,8 +768,8 @@ int bialign_batch_wait(bialign_batch* b) {
   HIP_TRY(hipSetDevice(b->eng->device));
   for (;;) {
     b->pending = false;
-    HIP_TRY(hipEventSynchronize(b->evs.back()));
     const int nchunks = (int)b->chunk_begin.size() - 1;
+    HIP_TRY(hipEventSynchronize(b->evs[3 * nchunks - 1]));  // (a re-planned batch may have fewer chunks than events)
     for (int c = 0; c < nchunks; ++c) {
       float f = 0, t = 0;
       HIP_TRY(hipEventElapsedTime(&f, b->evs[3 * c], b->evs[3 * c + 1]));

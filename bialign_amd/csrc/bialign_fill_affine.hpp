@@ -569,9 +569,9 @@ __global__ void __launch_bounds__(64 * TW) fill_affine_kernel(const DeviceBatch 
 #pragma unroll
         for (int q = 0; q < 9; ++q) {
           int e = M[q] - pk_base;
-          if (pack_corner(W, q, bb)) {
+          if (pack_corner(W, q, bb)) {  // 0xffff is the -2^30 mark here: a finite value must stay below it
             const bool ng = M[q] == NEG;
-            pk_acc |= ng ? 0 : e;
+            pk_acc |= ng ? 0 : e + 1;
             e = ng ? 0xffff : e;
           } else {
             pk_acc |= e;
@@ -600,7 +600,10 @@ __global__ void __launch_bounds__(64 * TW) fill_affine_kernel(const DeviceBatch 
           }
         }
         if (bb == W - 1) {  // an offset that does not fit 16 bits (or collides with the -2^30 mark): the host falls back
-          const bool bad = act_row && !ghost && live && (unsigned)pk_acc >= 0xffffu;
+          const bool bad = act_row && !ghost && live && (unsigned)pk_acc > 0xffffu;
+#ifdef BIALIGN_DEBUG_PACK
+          if (bad) printf("pack overflow: pair %d step %d lane %d row %d col %d k %d acc %x base %d M8 %d n %d m %d\n", pid, g, L, i, jj, i + aa - S, pk_acc, pk_base, M[8], n, m);
+#endif
           if (__builtin_amdgcn_ballot_w64(bad) != 0 && L == 0) atomicOr(A.errflag, 2);
         }
       }

@@ -16,8 +16,17 @@ CASES = [
     ("protein 1024 x512 s=1 non-affine", synth.protein_batch(1024, 512),
      dict(synth.PROTEIN_PARAMS, gap_opening_cost=0, gap_cost=-200, shift_cost=-250, max_shift=1)),
 ]
-for name, pairs, params in CASES:
-    b = make_batch(pairs, params)
+EXTRA = [  # reduced-storage sweeps of the same engine
+    ("cfg2 shape, score-only", synth.protein_batch(1024, 512), dict(synth.PROTEIN_PARAMS), dict(score_only=True)),
+    ("cfg4 full, score-only", synth.rna_batch(256, 2000), dict(synth.RNA_PARAMS, max_shift=2), dict(score_only=True)),
+    ("256 protein x512 s=1, lean traceback", synth.protein_batch(256, 512), dict(synth.PROTEIN_PARAMS), dict(lean_trace=True)),
+]
+if os.environ.get("PERF_ONLY"):  # e.g. PERF_ONLY="s=3,s=0,non-affine,score-only,lean" under rocprofv3 --pmc
+    keys = os.environ["PERF_ONLY"].split(",")
+    CASES = [c for c in CASES if any(k in c[0] for k in keys)]
+    EXTRA = [c for c in EXTRA if any(k in c[0] for k in keys)]
+for name, pairs, params, *kw in CASES + EXTRA:
+    b = make_batch(pairs, params, **(kw[0] if kw else {}))
     b.run(); b.run()
     t = b.timing(); info = b.info
     nl = 36 if info["affine"] else 4
