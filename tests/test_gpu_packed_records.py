@@ -47,6 +47,20 @@ def test_default_policy_full_layers(n, m, s, seed):
     check(synth.protein_pair(4000 + seed, n, m), dict(synth.PROTEIN_PARAMS, max_shift=s))
 
 
+@pytest.mark.parametrize("seed", range(6))
+def test_odd_valued_scores_stay_packed(seed):
+    """Scores with all kinds of low bits (the OR of a lane's offsets may then be 0xffff without any offset being out of
+    range): packed, no repeat, every cell equal to the oracle."""
+    rng = np.random.default_rng(900 + seed)
+    s = 1 + seed % 3
+    params = dict(synth.PROTEIN_PARAMS, max_shift=s, simmatrix=None, sequence_match_similarity=int(rng.integers(50, 999)),
+                  sequence_mismatch_similarity=-int(rng.integers(1, 499)), structure_weight=int(rng.integers(1, 1111)),
+                  gap_opening_cost=-int(rng.integers(1, 333)), gap_cost=-int(rng.integers(1, 277)),
+                  shift_cost=-int(rng.integers(1, 311)))
+    got = check(synth.protein_pair(4900 + seed, 170, 190), params)
+    assert got["timing"]["recovered_runs"] == 0
+
+
 @pytest.mark.parametrize("n,m,s", [(21, 120, 1), (300, 95, 1), (12, 100, 2)])
 def test_default_policy_leaves_short_sweeps_alone(n, m, s):
     check(synth.protein_pair(4050 + n, n, m), dict(synth.PROTEIN_PARAMS, max_shift=s), expect_packed=False)
@@ -89,7 +103,7 @@ def test_dense_mu2_packed(s):
     params = dict(synth.RNA_PARAMS, max_shift=s)
     b = make_batch(pairs, params, mu2_dense=tabs)
     b.run()
-    assert b.timing()["packed_records"]
+    assert b.timing()["packed_records"] and b.timing()["recovered_runs"] == 0
     scores = b.scores()
     traces, ok = b.traces()
     for t, (pair, (n, m)) in enumerate(zip(pairs, shapes)):
