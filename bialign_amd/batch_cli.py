@@ -67,6 +67,17 @@ def pair_block(idx, rec, params, score, trace, complete, verbose):
 
 
 def main(argv=None):
+    """Engine refusals (e.g. --score_only with --max_shift above 5, scores outside the int32 window) end like the
+    reference's own input errors (pyx:207-210): ``ERROR: <text>`` and exit status 255, not a Python traceback."""
+    from ._lib import BialignError
+    try:
+        return _main(argv)
+    except BialignError as e:
+        print("ERROR: " + e.message)
+        sys.exit(-1)
+
+
+def _main(argv=None):
     args = build_parser().parse_args(argv)
     params = {k: v for k, v in vars(args).items() if k not in ("pairs", "verbose", "score_only")}
     records = read_pairs(args.pairs)

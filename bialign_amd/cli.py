@@ -71,8 +71,13 @@ def main(argv=None):
         print("Available modes: " + ", ".join(bialignment.BiAligner.outmodes.keys()))
         print()
         sys.exit()
-    for line in bialign(**vars(args)):
-        print(line)
+    from ._lib import BialignError
+    try:
+        for line in bialign(**vars(args)):
+            print(line)
+    except BialignError as e:  # an engine refusal (scores outside the int32 window, molecules beyond the LDS staging):
+        print("ERROR: " + e.message)  # reported like the reference's own input errors (pyx:207-210), not as a traceback
+        sys.exit(-1)
 
 
 if __name__ == "__main__":

@@ -221,14 +221,14 @@ int launch_fill_affine_t(bialign_batch* b, const DeviceBatch& v, int first, int 
 
 // One-wave workgroups of the cross-CU kernel <S, LEAN> the device can hold at once, from the runtime's
 // occupancy calculation for the actual code object (registers, LDS): the cap of a cross-CU grid.
-template <int S, bool LEAN, int TW = 1>
+template <int S, bool LEAN, int TW = 1, bool DENSE = false>
 int xcu_resident_blocks(bialign_batch* b) {
-  int& cached = b->xcu_resident[(LEAN ? 1 : 0) + (TW == 8 ? 2 : 0)];
+  int& cached = b->xcu_resident[(LEAN ? 1 : 0) + (TW == 8 ? 2 : 0)];  // (a batch is either DENSE or not)
   if (cached >= 0) return cached;
   cached = 0;
   if constexpr (S <= 3 && (TW == 1 || S == 2)) {
     if (TW == 8 && !diet8_available(b)) return cached;
-    auto kern = fill_affine_kernel<S, true, TW, true, false, LEAN>;
+    auto kern = fill_affine_kernel<S, true, TW, true, DENSE, LEAN>;
     const size_t lds = TW == 8 ? b->lds_diet8 : b->lds_base + b->lds_per_wave;
     if (lds > 64 * 1024 &&
         hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
@@ -252,19 +252,25 @@ int launch_fill_affine_l(bialign_batch* b, const DeviceBatch& v, int first, int 
     return b->dense ? launch_fill_affine_t<S, false, 1, false, true, LEAN>(b, v, first, count, 1)
                     : launch_fill_affine_t<S, false, 1, false, false, LEAN>(b, v, first, count, 1);
   }
-  const bool xcu_ok = !b->dense && !b->no_xcu;
-  const TeamShape ts = team_shape(b, first, count, xcu_ok ? xcu_resident_blocks<S, LEAN>(b) : 0,
-                                  xcu_ok ? xcu_resident_blocks<S, LEAN, 8>(b) : 0);
+  const bool xcu_ok = !b->no_xcu;
+  const TeamShape ts = b->dense ? team_shape(b, first, count, xcu_ok ? xcu_resident_blocks<S, LEAN, 1, true>(b) : 0, 0)
+                                : team_shape(b, first, count, xcu_ok ? xcu_resident_blocks<S, LEAN>(b) : 0,
+                                             xcu_ok ? xcu_resident_blocks<S, LEAN, 8>(b) : 0);
   b->last_team = ts.waves() * (ts.gw > 1 ? -1 : 1);
-  if (b->dense) {
+  if (b->dense) {  // dense-mu2 kernels: one-wave cross-CU teams, in-workgroup teams of 4 and 2, one wave
     if constexpr (S >= 1 && S <= BIALIGN_MAX_SHIFT_PACKED && !LEAN) {
       if (b->pack_now()) {
+        if (ts.gw > 1) return launch_fill_affine_t<S, true, 1, true, true, false, true>(b, v, first, count, ts.gw);
+        b->last_team = std::min(ts.tw, 4);
+        if (ts.tw >= 4) return launch_fill_affine_t<S, true, 4, false, true, false, true>(b, v, first, count, 1);
         if (ts.tw >= 2) return launch_fill_affine_t<S, true, 2, false, true, false, true>(b, v, first, count, 1);
-        b->last_team = 1;
         return launch_fill_affine_t<S, true, 1, false, true, false, true>(b, v, first, count, 1);
       }
     }
     if constexpr (S <= 3) {
+      if (ts.gw > 1) return launch_fill_affine_t<S, true, 1, true, true, LEAN>(b, v, first, count, ts.gw);
+      b->last_team = std::min(ts.tw, 4);
+      if (ts.tw >= 4) return launch_fill_affine_t<S, true, 4, false, true, LEAN>(b, v, first, count, 1);
       if (ts.tw >= 2) return launch_fill_affine_t<S, true, 2, false, true, LEAN>(b, v, first, count, 1);
     }
     b->last_team = 1;

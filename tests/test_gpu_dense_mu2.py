@@ -117,6 +117,34 @@ def test_dense_full_layers_vs_oracle(n, m, s, seed, ov, team, monkeypatch):
         np.testing.assert_array_equal(g, e)
 
 
+@pytest.mark.parametrize("n,m,s,seed,team,lean", [(170, 400, 1, 81, "4", False), (330, 650, 1, 82, "x6", False), (100, 300, 2, 83, "4", False),
+                                                   (200, 400, 2, 84, "x5", False), (90, 400, 3, 85, "x3", False),
+                                                   (170, 400, 1, 86, "4", True), (330, 650, 1, 87, "x6", True)])
+def test_dense_wider_teams(n, m, s, seed, team, lean, monkeypatch):
+    """Dense mu2 with four waves per workgroup and with cross-CU teams (round 2; before: two waves at most)."""
+    from oracle import oracle
+    from bialign_amd.batch import make_batch
+    monkeypatch.setenv("BIALIGN_TEAM", team)
+    pair = synth.protein_pair(seed, n, m)
+    tab = random_table(np.random.default_rng(seed), n, m, -400, 1300)
+    params = dict(synth.PROTEIN_PARAMS, max_shift=s)
+    ref = oracle_dense(pair, tab, params)
+    if lean:   # score-only storage: the score against the oracle
+        b = make_batch([pair], params, mu2_dense=[tab], score_only=True)
+        b.run()
+        t, score = b.timing(), int(b.scores()[0])
+        b.close()
+        assert score == ref["score"]
+    else:
+        got = dense_solve([pair], [tab], params, layers_of=0)
+        t = got["timing"]
+        assert got["scores"][0] == ref["score"] and got["traces"][0] == oracle.trace_to_lists(ref["trace"])
+        assert got["complete"][0] == ref["complete"]
+        for g, e in zip(oracle.band_values(got["layers"], n, m, s), oracle.band_values(ref["layers"], n, m, s)):
+            np.testing.assert_array_equal(g, e)
+    assert t["waves_per_pair"] == int(team.lstrip("x")) and t["cross_cu"] == team.startswith("x")
+
+
 def test_dense_ragged_batch_and_chunking():
     from oracle import oracle
     rng = np.random.default_rng(80)
