@@ -190,6 +190,20 @@ def test_batch_cli_equals_single_pair_cli(tmp_path, capsys):
         assert ("SCORE: " + cols[3]) in blocks[t]
 
 
+def test_cli_reports_engine_refusals_like_input_errors(tmp_path, capsys):
+    """--score_only beyond the tiled band and scores outside the int32 window: "ERROR: ..." and exit, no traceback."""
+    from bialign_amd import batch_cli, cli
+    tsv = tmp_path / "pairs.tsv"
+    tsv.write_text("a\tARND\tHHEE\tb\tARNE\tHHEC\n")
+    with pytest.raises(SystemExit) as e:
+        batch_cli.main([str(tsv), "--type", "Protein", "--gap_opening_cost", "-150", "--max_shift", "8", "--score_only"])
+    assert e.value.code == -1 and capsys.readouterr().out.startswith("ERROR: ")
+    with pytest.raises(SystemExit) as e:
+        cli.main(["ARND", "ARNE", "--strA", "HHEE", "--strB", "HHEC", "--type", "Protein", "--gap_opening_cost", "-150",
+                  "--structure_weight", str(1 << 27)])
+    assert e.value.code == -1 and "ERROR: " in capsys.readouterr().out
+
+
 def test_c_abi_error_paths():
     """Bad arguments come back as negative codes with a message; nothing falls back to a CPU path."""
     import ctypes

@@ -7,8 +7,13 @@ from bialign_amd.engine import default_engine
 E = lambda k, d: int(os.environ.get(k, d))
 pairs = synth.rna_batch(E("AB_PAIRS", 64), E("AB_LEN", 2000))
 params = dict(synth.RNA_PARAMS, max_shift=E("AB_S", 2))
+tabs = None
+if E("AB_DENSE", 0):  # dense mu2 (the predicted-structure form): one random int32 table per pair
+    import numpy as np
+    rng = np.random.default_rng(5)
+    tabs = [rng.integers(0, 400, size=(len(p[0]), len(p[1]))).astype(np.int32) for p in pairs]
 for cycle in range(E("AB_CYCLES", 3)):
-    b = make_batch(pairs, params, score_only=bool(E("AB_LEAN", 0)), lean_trace=bool(E("AB_LEANTRACE", 0)))
+    b = make_batch(pairs, params, score_only=bool(E("AB_LEAN", 0)), lean_trace=bool(E("AB_LEANTRACE", 0)), mu2_dense=tabs)
     ts = []
     for _ in range(3):
         b.run(); ts.append(b.timing()["fill_ms"])
