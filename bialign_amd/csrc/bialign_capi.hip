@@ -37,7 +37,7 @@ TeamShape team_shape(const bialign_batch* b, int first, int count, int xcu_resid
   TeamShape ts;
   const int W = 2 * b->S + 1, R = 64 / W;
   const int lag = 2 * (R - 1) + 2 * ghost_blk(b->S) + 16;
-  int fit_exact = 32;  // largest team the pairs of this launch allow: T*lag + 64 <= P (P >= 256), two strips per wave
+  int fit_exact = PROG_WORDS;  // largest team the pairs of this launch allow: T*lag + 64 <= P (P >= 256), two strips per wave
   for (int t = first; t < first + count; ++t) {
     const PairDesc& d = b->pairs[b->order[t]];
     const int by_period = d.P >= 256 ? (d.P - 64) / lag : 1;

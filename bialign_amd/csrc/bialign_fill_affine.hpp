@@ -229,7 +229,7 @@ __global__ void __launch_bounds__(64 * TW) fill_affine_kernel(const DeviceBatch 
   //  54 -> 96 ms on a config-4 chunk, and wrong: lines then mix write-through and write-back sectors.)
   const bool wt_lane = to_other_cu;
   const bool from_other_cu = XCU && (TW == 1 || wl == 0);      // this wave's predecessor runs on another CU
-  int32_t* const prog_glb = XCU ? A.prog + (int64_t)slot * 64 : nullptr;
+  int32_t* const prog_glb = XCU ? A.prog + (int64_t)slot * PROG_WORDS : nullptr;
   auto prog_get = [&](int idx) __attribute__((always_inline)) -> int {
     if (from_other_cu) return __hip_atomic_load(prog_glb + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return prog_lds[XCU ? wl - 1 : idx];

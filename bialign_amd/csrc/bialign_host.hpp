@@ -202,8 +202,8 @@ int launch_fill_affine_t(bialign_batch* b, const DeviceBatch& v, int first, int 
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   if (XCU) {
-    if (b->d_prog.n < (size_t)count * 64) HIP_TRY(b->d_prog.alloc((size_t)count * 64));
-    HIP_TRY(hipMemsetAsync(b->d_prog.p, 0, (size_t)count * 64 * sizeof(int32_t), b->eng->stream));
+    if (b->d_prog.n < (size_t)count * PROG_WORDS) HIP_TRY(b->d_prog.alloc((size_t)count * PROG_WORDS));
+    HIP_TRY(hipMemsetAsync(b->d_prog.p, 0, (size_t)count * PROG_WORDS * sizeof(int32_t), b->eng->stream));
     w.prog = b->d_prog.p;
     w.spin_limit = b->xcu_spin_limit;
     b->used_xcu = true;

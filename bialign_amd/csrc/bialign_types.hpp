@@ -7,6 +7,7 @@ constexpr int32_t NEG = -(1 << 30);                 // reference -infinity
 constexpr int32_t SENT = -(1 << 30) - (1 << 29);    // "guard failed" marker
 constexpr int32_t THRESH = -(1 << 30) - (1 << 28);  // below: no valid case
 constexpr int NCOL = 65;                            // 64 lanes + 1 sentinel column
+constexpr int PROG_WORDS = 256;                     // cross-CU teams: progress words per pair = largest team
 typedef int v4i __attribute__((ext_vector_type(4)));
 
 struct PairDesc {
@@ -44,7 +45,7 @@ struct DeviceBatch {
   int32_t* complete;    // [npairs]
   int32_t* errflag;     // [1] sticky device-side error (team protocol timeout)
   const int32_t* mu2_dense;  // dense-mu2 mode: mu2(k,l) tables (else nullptr: LOOKUP form)
-  int32_t* prog;        // cross-CU teams: [pairs in launch][64] progress words, zeroed per launch
+  int32_t* prog;        // cross-CU teams: [pairs in launch][PROG_WORDS] progress words, zeroed per launch
   int32_t team;         // cross-CU teams: workgroups (= waves) per pair
   int32_t* scratch;     // lean traceback: full records of resw_k strips per pair
   TraceState* tstate;   // lean traceback: [npairs]

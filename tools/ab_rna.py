@@ -7,6 +7,8 @@ from bialign_amd.engine import default_engine
 E = lambda k, d: int(os.environ.get(k, d))
 pairs = synth.rna_batch(E("AB_PAIRS", 64), E("AB_LEN", 2000))
 params = dict(synth.RNA_PARAMS, max_shift=E("AB_S", 2))
+if E("AB_LINEAR", 0):  # the one-layer recurrence with the CLI's default costs
+    params.update(gap_opening_cost=0, gap_cost=-200, shift_cost=-250)
 tabs = None
 if E("AB_DENSE", 0):  # dense mu2 (the predicted-structure form): one random int32 table per pair
     import numpy as np
@@ -21,7 +23,7 @@ for cycle in range(E("AB_CYCLES", 3)):
     b_scores = b.scores()
     print(f"cycle {cycle}: fill ms " + " ".join(f"{x:.2f}" for x in ts) +
           f"   team {t['waves_per_pair']}{'x' if t['cross_cu'] else ''} chunks {b.info['nchunks']}  "
-          f"{b.info['cells'] * 36 / min(ts) / 1e9:.2f} TB/s", flush=True)
+          f"{b.info['cells'] * (36 if b.info['affine'] else 4) / min(ts) / 1e9:.2f} TB/s  {b.info['cells'] / min(ts) / 1e6:.1f} Gcells/s", flush=True)
     b.close()
     default_engine().trim()
     if cycle == 0:
