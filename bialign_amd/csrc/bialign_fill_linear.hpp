@@ -10,17 +10,20 @@ namespace bialign {
 // later and kept in registers for the cases that need them 2 or 3 steps later
 // (age of offset o = o0 + o1 + o2).
 // ---------------------------------------------------------------------------
-template <int S, int TW, bool DENSE = false, bool LEAN = false, bool RESW = false>
+//   XCU: the team is A.team one-wave workgroups on any CUs (progress words in HBM, write-through
+//   stores), as in fill_affine_kernel -- for a handful of long pairs, e.g. one pair from the CLI.
+template <int S, int TW, bool DENSE = false, bool LEAN = false, bool RESW = false, bool XCU = false>
 __global__ void __launch_bounds__(64 * TW) fill_linear_kernel(const DeviceBatch A) {
+  static_assert(!XCU || (TW == 1 && !RESW), "cross-CU teams are built from one-wave workgroups");
   using G_ = Geo<S>;
   using R_ = Rec<S, 1, LEAN>;
   constexpr int W = G_::W, R = G_::R, RR = G_::RR, PADB = G_::PADB;
   constexpr int NV = W, ND = R_::ND, NCH4 = R_::NCH4, TAIL = R_::TAIL, RECDW = R_::RECDW;
   extern __shared__ __align__(16) int32_t smem[];
 
-  constexpr int T = TW;  // team = the workgroup's waves (see fill_affine_kernel)
+  const int T = XCU ? A.team : TW;  // team = the workgroup's waves, or A.team one-wave workgroups (see fill_affine_kernel)
   static_assert(!RESW || (TW == 1 && !LEAN), "strip re-sweeps (see fill_affine_kernel): one wave, full records");
-  const int pslot = RESW ? blockIdx.x / A.resw_k : blockIdx.x;
+  const int pslot = XCU ? blockIdx.x / T : (RESW ? blockIdx.x / A.resw_k : blockIdx.x);
   const int pid = A.order[pslot];
   const PairDesc pd = A.pairs[pid];
   const int n = pd.n, m = pd.m, P = pd.P;
@@ -34,7 +37,8 @@ __global__ void __launch_bounds__(64 * TW) fill_linear_kernel(const DeviceBatch 
     jlim = ts0.started ? ts0.j : m;  // the walk never moves right: no strip of this round is entered beyond its column
   }
   const int L = threadIdx.x & 63;
-  const int w = TW == 1 ? 0 : __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wl = TW == 1 ? 0 : __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave in workgroup
+  const int w = XCU ? (int)(blockIdx.x - pslot * T) : wl;                              // wave in team
   const int il = L / W, aa = L - il * W;
   const bool live = L < R * W;
   const bool ghost = (il == 0);
@@ -45,9 +49,9 @@ __global__ void __launch_bounds__(64 * TW) fill_linear_kernel(const DeviceBatch 
   using GF = GhostFeed<S, 1, LEAN || RESW>;
   using MF = Mu2Feed<S>;
   constexpr int PERW = GF::RING_DW + NV * NCOL + (DENSE ? MF::RING_DW : 0);
-  v4i* ring = reinterpret_cast<v4i*>(smem + w * GF::RING_DW);
-  int32_t* xch = smem + TW * GF::RING_DW + w * (NV * NCOL);
-  int32_t* mu2ring = smem + TW * (GF::RING_DW + NV * NCOL) + w * MF::RING_DW;
+  v4i* ring = reinterpret_cast<v4i*>(smem + wl * GF::RING_DW);
+  int32_t* xch = smem + TW * GF::RING_DW + wl * (NV * NCOL);
+  int32_t* mu2ring = smem + TW * (GF::RING_DW + NV * NCOL) + wl * MF::RING_DW;
   volatile int32_t* prog = smem + TW * PERW;  // [16] steps with acknowledged stores
   int32_t* s1 = smem + TW * PERW + 16;
   int32_t* s2 = s1 + k1 * k1;
@@ -105,16 +109,29 @@ __global__ void __launch_bounds__(64 * TW) fill_linear_kernel(const DeviceBatch 
 #pragma unroll
   for (int bb = 0; bb < W; ++bb) lw1[bb] = lw2[bb] = lwp1[bb] = l11[bb] = selfM[bb] = ghostM[bb] = SENT;
   const uint32_t ring_lds = __builtin_amdgcn_readfirstlane(
-      (uint32_t)(uintptr_t)(__attribute__((address_space(3))) int32_t*)smem) + w * GF::RING_DW * 4;
+      (uint32_t)(uintptr_t)(__attribute__((address_space(3))) int32_t*)smem) + wl * GF::RING_DW * 4;
 
-  // team protocol, as in fill_affine_kernel (in-workgroup form)
+  // team protocol, as in fill_affine_kernel
   int blk_q = 0, blk_rem = 0;
   bool team_failed = false;
+  int32_t* const prog_glb = XCU ? A.prog + (int64_t)pslot * PROG_WORDS : nullptr;
+  auto prog_get = [&](int idx) __attribute__((always_inline)) -> int {
+    if (XCU) return __hip_atomic_load(prog_glb + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return prog[idx];
+  };
+  auto prog_put = [&](int v) __attribute__((always_inline)) {  // lane 0 only
+    if (XCU)
+      __hip_atomic_store(prog_glb + w, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else
+      prog[w] = v;
+  };
+  int seen_prog = -0x40000000;  // the partner's progress as last read (it only grows)
   auto wait_partner = [&](int h_last) __attribute__((always_inline)) {
     if (T == 1 || team_failed) return;
     const int src = w == 0 ? T - 1 : w - 1;
     const int need = h_last + 2 * (R - 1) + 1 - (w == 0 ? P : 0);
-    for (int spin = 0; prog[src] < need; ++spin) {
+    if (seen_prog >= need) return;
+    for (int spin = 0; (seen_prog = prog_get(src)) < need; ++spin) {
       if (spin > A.spin_limit) {
         if (L == 0) atomicOr(A.errflag, 1);
         team_failed = true;
@@ -125,7 +142,7 @@ __global__ void __launch_bounds__(64 * TW) fill_linear_kernel(const DeviceBatch 
   };
   const uint32_t mu2_lds = __builtin_amdgcn_readfirstlane(
       (uint32_t)(uintptr_t)(__attribute__((address_space(3))) int32_t*)smem) +
-      (TW * (GF::RING_DW + NV * NCOL) + w * MF::RING_DW) * 4;
+      (TW * (GF::RING_DW + NV * NCOL) + wl * MF::RING_DW) * 4;
   const int32_t* const mu2tab = DENSE ? A.mu2_dense + pd.mu2_off : nullptr;
   int mu2w[W];
 #pragma unroll
@@ -145,7 +162,7 @@ __global__ void __launch_bounds__(64 * TW) fill_linear_kernel(const DeviceBatch 
     const int gt = g & (GF::BLK - 1), ghalf = (g / GF::BLK) & 1;
     if (gt == 0) {
       GF::wait_block(vm_younger);
-      if (T > 1 && L == 0) prog[w] = g - GF::BLK;  // see the affine kernel
+      if (T > 1 && L == 0) prog_put(g - GF::BLK);  // see the affine kernel
       prefetch_block(g + GF::BLK, ghalf ^ 1, jj + GF::BLK);
       vm_younger = 0;
     }
@@ -230,11 +247,16 @@ __global__ void __launch_bounds__(64 * TW) fill_linear_kernel(const DeviceBatch 
       for (int c = 0; c < NCH4; ++c) {
         v4i v;
         v.x = outv[4 * c]; v.y = outv[4 * c + 1]; v.z = outv[4 * c + 2]; v.w = outv[4 * c + 3];
-        *reinterpret_cast<v4i*>(dst + c * R_::CH + slot * 4) = v;
+        store_chunk<XCU>(dst + c * R_::CH + slot * 4, v, true);
       }
       if (LEAN) {
 #pragma unroll
-        for (int t = 0; t < TAIL; ++t) dst[NCH4 * R_::CH + slot * TAIL + t] = outv[4 * NCH4 + t];
+        for (int t = 0; t < TAIL; ++t) {
+          if (XCU)
+            __hip_atomic_store(dst + NCH4 * R_::CH + slot * TAIL + t, outv[4 * NCH4 + t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          else
+            dst[NCH4 * R_::CH + slot * TAIL + t] = outv[4 * NCH4 + t];
+        }
       }
     }
     if (!LEAN && __builtin_amdgcn_ballot_w64(tile_act && !ghost) != 0 && (T == 1 || rec <= rec_last)) {
@@ -242,7 +264,12 @@ __global__ void __launch_bounds__(64 * TW) fill_linear_kernel(const DeviceBatch 
       const int tslot = (live && !ghost) ? L - W : R_::SL + (L < W ? L : W + (L - R * W));
       int32_t* dst = sto + (int64_t)rec * RECDW;
 #pragma unroll
-      for (int t = 0; t < TAIL; ++t) dst[NCH4 * R_::CH + tslot * TAIL + t] = outv[4 * NCH4 + t];
+      for (int t = 0; t < TAIL; ++t) {
+        if (XCU)
+          __hip_atomic_store(dst + NCH4 * R_::CH + tslot * TAIL + t, outv[4 * NCH4 + t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else
+          dst[NCH4 * R_::CH + tslot * TAIL + t] = outv[4 * NCH4 + t];
+      }
     }
     ++jj;
     if (!RESW && jj == P) {
@@ -254,7 +281,7 @@ __global__ void __launch_bounds__(64 * TW) fill_linear_kernel(const DeviceBatch 
   }
   if (T > 1) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (L == 0) prog[w] = 0x7fffffff;
+    if (L == 0) prog_put(0x7fffffff);
   }
 }
 

@@ -379,27 +379,65 @@ int launch_traceback_affine(const bialign_batch* b, const DeviceBatch& v, int fi
   return BIALIGN_OK;
 }
 
-template <int S, int TW, bool DENSE = false, bool LEAN = false>
-int launch_fill_linear_t(bialign_batch* b, const DeviceBatch& v, int first, int count) {
+template <int S, int TW, bool DENSE = false, bool LEAN = false, bool XCU = false>
+int launch_fill_linear_t(bialign_batch* b, const DeviceBatch& v, int first, int count, int gw = 1) {
   DeviceBatch w = v;
   w.order = v.order + first;
-  auto kern = fill_linear_kernel<S, TW, DENSE, LEAN>;
+  w.team = gw;
+  b->packed_layers = false;
+  auto kern = fill_linear_kernel<S, TW, DENSE, LEAN, false, XCU>;
   const size_t lds = b->lds_base + (size_t)TW * b->lds_per_wave;
   if (lds > 64 * 1024)
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(kern, dim3(count), dim3(64 * TW), lds, b->eng->stream, w);
-  HIP_TRY(hipGetLastError());
+  if (XCU) {  // as in launch_fill_affine_t
+    if (b->d_prog.n < (size_t)count * PROG_WORDS) HIP_TRY(b->d_prog.alloc((size_t)count * PROG_WORDS));
+    HIP_TRY(hipMemsetAsync(b->d_prog.p, 0, (size_t)count * PROG_WORDS * sizeof(int32_t), b->eng->stream));
+    w.prog = b->d_prog.p;
+    w.spin_limit = b->xcu_spin_limit;
+    b->used_xcu = true;
+    if (int rc = xcu_serial_begin(b->eng)) return rc;
+  }
+  hipLaunchKernelGGL(kern, dim3(count * (XCU ? gw : 1)), dim3(64 * TW), lds, b->eng->stream, w);
+  const hipError_t launched = hipGetLastError();
+  if (XCU) {
+    const int rc = xcu_serial_end(b->eng);
+    if (launched == hipSuccess && rc) return rc;
+  }
+  HIP_TRY(launched);
   return BIALIGN_OK;
+}
+
+// one-wave workgroups of the one-layer cross-CU kernel the device holds at once
+template <int S, bool LEAN>
+int xcu_resident_linear(bialign_batch* b) {
+  int& cached = b->xcu_resident[LEAN ? 1 : 0];
+  if (cached >= 0) return cached;
+  cached = 0;
+  auto kern = fill_linear_kernel<S, 1, false, LEAN, false, true>;
+  const size_t lds = b->lds_base + b->lds_per_wave;
+  if (lds > 64 * 1024 &&
+      hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+    (void)hipGetLastError();
+    return cached;
+  }
+  int per_cu = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), 64, lds) != hipSuccess) {
+    (void)hipGetLastError();
+    return cached;
+  }
+  return cached = per_cu * b->eng->num_cu;
 }
 
 template <int S, bool LEAN>
 int launch_fill_linear_l(bialign_batch* b, const DeviceBatch& v, int first, int count) {
-  const TeamShape ts = team_shape(b, first, count, 0);
-  b->last_team = ts.tw;
+  const bool xcu_ok = !b->dense && !b->no_xcu;
+  const TeamShape ts = team_shape(b, first, count, xcu_ok ? xcu_resident_linear<S, LEAN>(b) : 0);
+  b->last_team = ts.waves() * (ts.gw > 1 ? -1 : 1);
   if (b->dense)
     return ts.tw >= 2 ? launch_fill_linear_t<S, 2, true, LEAN>(b, v, first, count)
                       : launch_fill_linear_t<S, 1, true, LEAN>(b, v, first, count);
+  if (ts.gw > 1) return launch_fill_linear_t<S, 1, false, LEAN, true>(b, v, first, count, ts.gw);
   switch (ts.tw) {
     case 8: return launch_fill_linear_t<S, 8, false, LEAN>(b, v, first, count);
     case 4: return launch_fill_linear_t<S, 4, false, LEAN>(b, v, first, count);

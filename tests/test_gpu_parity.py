@@ -209,9 +209,12 @@ def test_dump_layers_of_any_pair_in_a_batch():
 
 
 @pytest.mark.parametrize("n,m,s,seed,team", [(300, 320, 1, 41, 2), (330, 650, 1, 42, 8), (200, 400, 2, 43, 4),
-                                              (420, 400, 0, 44, 2), (150, 300, 3, 45, 2)])
+                                              (420, 400, 0, 44, 2), (150, 300, 3, 45, 2),
+                                              (330, 650, 1, 46, "x8"), (700, 1300, 1, 47, "x16"), (200, 500, 2, 48, "x7"),
+                                              (90, 400, 4, 49, "x3"), (420, 400, 0, 50, "x2")])
 def test_team_sweep_linear_full_layers(n, m, s, seed, team, monkeypatch):
-    """The non-affine (13-case) fill with T waves per pair: the layer, trace and score."""
+    """The non-affine (13-case) fill with T waves per pair, in one workgroup or (xN) as one-wave workgroups on N
+    CUs: the layer, trace and score."""
     from oracle import oracle
     monkeypatch.setenv("BIALIGN_TEAM", str(team))
     sa, sb, ta, tb = synth.protein_pair(seed, n, m)
@@ -219,7 +222,7 @@ def test_team_sweep_linear_full_layers(n, m, s, seed, team, monkeypatch):
     rec = dict(seqA=sa, seqB=sb, strA=ta, strB=tb, params=params)
     ref = oracle.solve(sa, sb, ta, tb, params)
     got = gpu_solve(rec, layers=True)
-    assert got["timing"]["waves_per_pair"] == team
+    assert got["timing"]["waves_per_pair"] == int(str(team).lstrip("x")) and got["timing"]["cross_cu"] == str(team).startswith("x")
     assert got["score"] == ref["score"] and got["trace"] == oracle.trace_to_lists(ref["trace"])
     for g, e in zip(oracle.band_values(got["layers"], n, m, s), oracle.band_values(ref["layers"], n, m, s)):
         np.testing.assert_array_equal(g, e)

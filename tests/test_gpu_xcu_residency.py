@@ -85,6 +85,20 @@ def test_lost_co_residency_is_recovered(s, monkeypatch):
     b.close()
 
 
+def test_one_layer_recurrence_recovers_too(monkeypatch):
+    """The non-affine sweep's cross-CU teams (a single long pair from the CLI's default parameters): same recovery."""
+    from bialign_amd.batch import make_batch
+    monkeypatch.setenv("BIALIGN_XCU_SPIN_LIMIT", "0")
+    params = dict(synth.PROTEIN_PARAMS, gap_opening_cost=0, gap_cost=-200, shift_cost=-250, max_shift=2)
+    pairs = [synth.protein_pair(995, 900, 1000)]
+    b = make_batch(pairs, params)
+    b.run()
+    t = b.timing()
+    assert t["recovered_runs"] == 1 and not t["cross_cu"]
+    assert batch_results(b) == oracle_results(pairs, params)
+    b.close()
+
+
 def test_dump_layers_recovers_too(monkeypatch):
     """dump_layers launches one pair on its own (a cross-CU team here): same recovery."""
     from oracle import oracle
