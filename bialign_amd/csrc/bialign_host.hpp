@@ -226,7 +226,7 @@ int xcu_resident_blocks(bialign_batch* b) {
   int& cached = b->xcu_resident[(LEAN ? 1 : 0) + (TW == 8 ? 2 : 0)];  // (a batch is either DENSE or not)
   if (cached >= 0) return cached;
   cached = 0;
-  if constexpr (S <= 3 && (TW == 1 || S == 2)) {
+  if constexpr ((DENSE ? S <= 3 : true) && (TW == 1 || S == 2)) {
     if (TW == 8 && !diet8_available(b)) return cached;
     auto kern = fill_affine_kernel<S, true, TW, true, DENSE, LEAN>;
     const size_t lds = TW == 8 ? b->lds_diet8 : b->lds_base + b->lds_per_wave;
@@ -293,9 +293,7 @@ int launch_fill_affine_l(bialign_batch* b, const DeviceBatch& v, int first, int 
   if constexpr (S == 2) {
     if (ts.gw > 1 && ts.tw == 8) return launch_fill_affine_t<S, true, 8, true, false, LEAN>(b, v, first, count, ts.gw);
   }
-  if constexpr (S <= 3) {
-    if (ts.gw > 1) return launch_fill_affine_t<S, true, 1, true, false, LEAN>(b, v, first, count, ts.gw);
-  }
+  if (ts.gw > 1) return launch_fill_affine_t<S, true, 1, true, false, LEAN>(b, v, first, count, ts.gw);
   if constexpr (S <= 2) {  // (s=2: the DIET layout)
     if (ts.tw == 8) return launch_fill_affine_t<S, true, 8, false, false, LEAN>(b, v, first, count, 1);
   }
