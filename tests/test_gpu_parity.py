@@ -124,7 +124,7 @@ def test_team_sweep_full_layers(n, m, s, seed, team, monkeypatch):
                                               (130, 300, 1, 35, 3), (210, 430, 1, 36, 5), (480, 930, 1, 37, 12),
                                               (200, 400, 2, 38, 7),
                                               (200, 500, 2, 34, 8), (420, 400, 0, 35, 2), (90, 400, 3, 36, 4),
-                                              (50, 200, 4, 37, 3), (60, 330, 4, 38, 6), (40, 180, 5, 39, 3)])
+                                              (50, 300, 4, 37, 3), (66, 330, 4, 38, 5), (40, 280, 5, 39, 3)])
 def test_cross_cu_team_full_layers(n, m, s, seed, team, monkeypatch):
     """The team spread over one-wave workgroups on different CUs / XCDs (write-through stores,
     progress words in HBM): every layer cell, trace and score."""
