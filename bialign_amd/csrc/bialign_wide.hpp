@@ -45,14 +45,23 @@ struct WideCtx {
   }
 };
 
-// Visit every lattice point of level D with the threads of this workgroup.
+// One pair is swept by A.team workgroups of WIDE_THREADS threads (the "parts" of the pair: block b -> pair b / team,
+// part b % team) on any CUs / XCDs; team = 1 for batches with many pairs.  Per-XCD L2s are not coherent, so layer
+// values travel like the tiled sweep's cross-CU teams do: write-through stores and sc1 loads, and a level is
+// closed by a counter in HBM (A.prog, one word per pair, zeroed per launch) that every part bumps once its
+// stores are acknowledged.  All parts of a launch must be resident at once (the host sizes the grid from the
+// runtime's occupancy figure); a part that waits longer than the spin limit raises the device flag and the host
+// repeats the run with one workgroup per pair.
+constexpr int WIDE_THREADS = 512;
+
+// Visit every lattice point of level D with the threads of all parts of the pair.
 template <typename F>
-__device__ __forceinline__ void wide_for_level(const WideCtx& c, int D, F&& f) {
+__device__ __forceinline__ void wide_for_level(const WideCtx& c, int D, int part, int parts, F&& f) {
   const int S = c.S, W = c.W, HW = (W + 1) / 2;
   // j = (D - 2i - (aa-S) - (bb-S)) / 2 must lie in [0, m]
   const int ilo = max(0, (D - 2 * c.m - 2 * S + 1) >> 1), ihi = min(c.n, (D + 2 * S) >> 1);
   const int items = (ihi - ilo + 1) * W * HW;
-  for (int t = threadIdx.x; t < items; t += blockDim.x) {
+  for (int t = part * WIDE_THREADS + threadIdx.x; t < items; t += parts * WIDE_THREADS) {
     const int hb = t % HW, aa = (t / HW) % W, i = ilo + t / (HW * W);
     const int bb = 2 * hb + ((D - aa) & 1);  // aa + bb must have D's parity
     if (bb >= W) continue;
@@ -64,20 +73,46 @@ __device__ __forceinline__ void wide_for_level(const WideCtx& c, int D, F&& f) {
   }
 }
 
-// Layers written at one level are read at the next ones by other waves of the workgroup:
-// write back / invalidate around the barrier (all waves share this CU's L2).
-__device__ __forceinline__ void wide_level_sync() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+// nine consecutive layer values (one cell's states), from L2 or beyond, never from this CU's L1; the compiler
+// keeps all of a point's loads in flight and waits once before the first use
+__device__ __forceinline__ void wide_load9(const int32_t* p, int (&v)[9]) {
+#pragma unroll
+  for (int q = 0; q < 9; ++q) v[q] = __hip_atomic_load(p + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void wide_store(int32_t* p, int v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // global_store_dword ... sc1: write-through
+}
+
+// Close a level: every part's stores are acknowledged, then all parts of the pair have said so.
+__device__ __forceinline__ void wide_level_sync(const DeviceBatch& A, int32_t* counter, int level, int parts, bool& failed) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  if (parts > 1) {
+    if (threadIdx.x == 0 && !failed) {
+      __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int need = (level + 1) * parts;
+      for (int spin = 0; __hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need; ++spin) {
+        if (spin > A.spin_limit) {  // a partner was never scheduled: fail fast, the host recovers
+          atomicOr(A.errflag, 1);
+          failed = true;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(8);
+      }
+    }
+    __syncthreads();
+  }
 }
 
 // ---------------------------------------------------------------------------
-// Affine fill (pyx:474-509), literal: per target state the fifteen cases of pyx:275-296.
+// Affine fill (pyx:474-509), literal: per target state the fifteen cases of pyx:275-296.  A point's fifteen
+// predecessor cells (one per nonzero offset in {0,1}^4) are loaded up front, nine states each: one memory
+// round trip per point.
 // ---------------------------------------------------------------------------
 template <int UNUSED = 0>  // (a template so that only bialign_wide.hip instantiates it)
-__global__ void __launch_bounds__(1024) fill_wide_affine_kernel(const DeviceBatch A, int S) {
-  const int pid = A.order[blockIdx.x];
+__global__ void __launch_bounds__(WIDE_THREADS) fill_wide_affine_kernel(const DeviceBatch A, int S) {
+  const int parts = A.team, slot = blockIdx.x / parts, part = blockIdx.x - slot * parts;
+  const int pid = A.order[slot];
   const PairDesc pd = A.pairs[pid];
   WideCtx c;
   c.n = pd.n; c.m = pd.m; c.S = S; c.W = 2 * S + 1;
@@ -88,14 +123,27 @@ __global__ void __launch_bounds__(1024) fill_wide_affine_kernel(const DeviceBatc
   c.lay = A.layers + pd.layer_off;
   const int n = c.n, m = c.m, W = c.W;
   const int beta = c.beta, gamma = c.gamma, delta = c.delta;
+  int32_t* const counter = A.prog + (int64_t)slot * PROG_WORDS;
+  bool failed = false;  // (thread 0: a level barrier timed out, no further waits)
 
   for (int D = 0; D <= 2 * (n + m); ++D) {
-    wide_for_level(c, D, [&](int i, int j, int k, int l, int aa, int bb) {
+    wide_for_level(c, D, part, parts, [&](int i, int j, int k, int l, int aa, int bb) {
       int32_t* out = c.lay + wide_dword(m, W, 9, i, j, aa, bb, 0);
       if (D == 0) {  // pyx:483-485
 #pragma unroll
-        for (int q = 0; q < 9; ++q) out[q] = q == 8 ? 0 : NEG;
+        for (int q = 0; q < 9; ++q) wide_store(out + q, q == 8 ? 0 : NEG);
         return;
+      }
+      // predecessor cells by offset code o0*8 + o1*4 + o2*2 + o3 (1..15); an invalid one (pyx:133-141) is not read
+      int pred[16][9];
+      bool ok[16];
+      ok[0] = false;
+#pragma unroll
+      for (int code = 1; code < 16; ++code) {
+        const int pi = i - ((code >> 3) & 1), pj = j - ((code >> 2) & 1), pk = k - ((code >> 1) & 1), pl = l - (code & 1);
+        ok[code] = c.valid(pi, pj, pk, pl);
+        const int32_t* src = ok[code] ? c.lay + wide_dword(m, W, 9, pi, pj, pk - pi + S, pl - pj + S, 0) : out;
+        wide_load9(src, pred[code]);
       }
       const int mu1 = c.mu1(i, j), mu2 = c.mu2(k, l);
 #pragma unroll
@@ -107,42 +155,33 @@ __global__ void __launch_bounds__(1024) fill_wide_affine_kernel(const DeviceBatc
           bool any = false;
           int best = NEG;  // pyx:299-303: no valid case -> exactly NEG
           auto take = [&](int v) { best = any ? (v > best ? v : best) : v; any = true; };
-          {  // group 1 (pyx:275-279): offset = the target state, all nine sources
-            const int pi = i - u0, pj = j - u1, pk = k - v0, pl = l - v1;
-            if (c.valid(pi, pj, pk, pl)) {
-              const int32_t* src = c.lay + wide_dword(m, W, 9, pi, pj, pk - pi + S, pl - pj + S, 0);
-              const int sh = hU == hV ? 0 : ((hU == 2 || hV == 2) ? 1 : 2);
-              const int base = delta * sh + valU + valV;
+          const int c1 = u0 * 8 + u1 * 4 + v0 * 2 + v1;  // group 1 (pyx:275-279): offset = the target state, all nine sources
+          if (ok[c1]) {
+            const int sh = hU == hV ? 0 : ((hU == 2 || hV == 2) ? 1 : 2);
+            const int base = delta * sh + valU + valV;
 #pragma unroll
-              for (int r = 0; r < 9; ++r) {
-                const int ra = r / 3, rb = r % 3;
-                take(src[r] + base + ((hU != 2 && ra != hU) ? beta : 0) + ((hV != 2 && rb != hV) ? beta : 0));
-              }
+            for (int r = 0; r < 9; ++r) {
+              const int ra = r / 3, rb = r % 3;
+              take(pred[c1][r] + base + ((hU != 2 && ra != hU) ? beta : 0) + ((hV != 2 && rb != hV) ? beta : 0));
             }
           }
-          {  // group 2 (pyx:284-290): offset (0,0,V), sources (U,h), h = M, X, Y
-            const int pk = k - v0, pl = l - v1;
-            if (c.valid(i, j, pk, pl)) {
-              const int32_t* src = c.lay + wide_dword(m, W, 9, i, j, pk - i + S, pl - j + S, 0);
-              const int base = delta * (v0 + v1) + valV;
+          const int c2 = v0 * 2 + v1;  // group 2 (pyx:284-290): offset (0,0,V), sources (U,h), h = M, X, Y
+          if (ok[c2]) {
+            const int base = delta * (v0 + v1) + valV;
 #pragma unroll
-              for (int h = 2; h >= 0; --h) take(src[3 * hU + h] + base + ((hV != 2 && h != hV) ? beta : 0));
-            }
+            for (int h = 2; h >= 0; --h) take(pred[c2][3 * hU + h] + base + ((hV != 2 && h != hV) ? beta : 0));
           }
-          {  // group 3 (pyx:291-296): offset (U,0,0), sources (h,V)
-            const int pi = i - u0, pj = j - u1;
-            if (c.valid(pi, pj, k, l)) {
-              const int32_t* src = c.lay + wide_dword(m, W, 9, pi, pj, k - pi + S, l - pj + S, 0);
-              const int base = delta * (u0 + u1) + valU;
+          const int c3 = u0 * 8 + u1 * 4;  // group 3 (pyx:291-296): offset (U,0,0), sources (h,V)
+          if (ok[c3]) {
+            const int base = delta * (u0 + u1) + valU;
 #pragma unroll
-              for (int h = 2; h >= 0; --h) take(src[3 * h + hV] + base + ((hU != 2 && h != hU) ? beta : 0));
-            }
+            for (int h = 2; h >= 0; --h) take(pred[c3][3 * h + hV] + base + ((hU != 2 && h != hU) ? beta : 0));
           }
-          out[3 * hU + hV] = best;
+          wide_store(out + 3 * hU + hV, best);
         }
       }
     });
-    wide_level_sync();
+    wide_level_sync(A, counter, D, parts, failed);
   }
 }
 
@@ -150,8 +189,9 @@ __global__ void __launch_bounds__(1024) fill_wide_affine_kernel(const DeviceBatc
 // Non-affine fill (pyx:443-471): thirteen cases (pyx:233-248), one layer.
 // ---------------------------------------------------------------------------
 template <int UNUSED = 0>
-__global__ void __launch_bounds__(1024) fill_wide_linear_kernel(const DeviceBatch A, int S) {
-  const int pid = A.order[blockIdx.x];
+__global__ void __launch_bounds__(WIDE_THREADS) fill_wide_linear_kernel(const DeviceBatch A, int S) {
+  const int parts = A.team, slot = blockIdx.x / parts, part = blockIdx.x - slot * parts;
+  const int pid = A.order[slot];
   const PairDesc pd = A.pairs[pid];
   WideCtx c;
   c.n = pd.n; c.m = pd.m; c.S = S; c.W = 2 * S + 1;
@@ -163,29 +203,38 @@ __global__ void __launch_bounds__(1024) fill_wide_linear_kernel(const DeviceBatc
   const int n = c.n, m = c.m, W = c.W;
   const int gamma = c.gamma, delta = c.delta, gD = gamma + delta;
   constexpr int OFF[13] = {15, 10, 5, 12, 3, 8, 4, 2, 1, 11, 7, 14, 13};  // o0*8+o1*4+o2*2+o3, generator order
+  int32_t* const counter = A.prog + (int64_t)slot * PROG_WORDS;
+  bool failed = false;  // (thread 0: a level barrier timed out, no further waits)
 
   for (int D = 0; D <= 2 * (n + m); ++D) {
-    wide_for_level(c, D, [&](int i, int j, int k, int l, int aa, int bb) {
+    wide_for_level(c, D, part, parts, [&](int i, int j, int k, int l, int aa, int bb) {
       int32_t* out = c.lay + wide_dword(m, W, 1, i, j, aa, bb, 0);
-      if (D == 0) { *out = 0; return; }  // zero-initialised storage (pyx:452)
+      if (D == 0) { wide_store(out, 0); return; }  // zero-initialised storage (pyx:452)
+      int pv[13];
+      bool ok[13];
+#pragma unroll
+      for (int t = 0; t < 13; ++t) {  // all thirteen predecessors in flight together
+        const int o0 = (OFF[t] >> 3) & 1, o1 = (OFF[t] >> 2) & 1, o2 = (OFF[t] >> 1) & 1, o3 = OFF[t] & 1;
+        const int pi = i - o0, pj = j - o1, pk = k - o2, pl = l - o3;
+        ok[t] = c.valid(pi, pj, pk, pl);
+        const int32_t* src = ok[t] ? c.lay + wide_dword(m, W, 1, pi, pj, pk - pi + S, pl - pj + S, 0) : out;
+        pv[t] = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
       const int mu1 = c.mu1(i, j), mu2 = c.mu2(k, l);
       bool any = false;
       int best = NEG;
 #pragma unroll
       for (int t = 0; t < 13; ++t) {
-        const int o0 = (OFF[t] >> 3) & 1, o1 = (OFF[t] >> 2) & 1, o2 = (OFF[t] >> 1) & 1, o3 = OFF[t] & 1;
-        const int pi = i - o0, pj = j - o1, pk = k - o2, pl = l - o3;
-        if (!c.valid(pi, pj, pk, pl)) continue;
+        if (!ok[t]) continue;
         const int use1 = (t == 0 || t == 3 || t == 11 || t == 12), use2 = (t == 0 || t == 4 || t == 9 || t == 10);
         const int kconst = t == 0 ? 0 : (t <= 2 ? 2 * gamma : (t <= 4 ? delta : gD));
-        const int v = c.lay[wide_dword(m, W, 1, pi, pj, pk - pi + S, pl - pj + S, 0)] + kconst + (use1 ? mu1 : 0) +
-                      (use2 ? mu2 : 0);
+        const int v = pv[t] + kconst + (use1 ? mu1 : 0) + (use2 ? mu2 : 0);
         best = any ? (v > best ? v : best) : v;
         any = true;
       }
-      *out = best;
+      wide_store(out, best);
     });
-    wide_level_sync();
+    wide_level_sync(A, counter, D, parts, failed);
   }
 }
 

@@ -65,6 +65,46 @@ def test_ragged_chunked_batch_vs_oracle(dense):
             assert bool(ok[t]) == ref["complete"]
 
 
+@pytest.mark.parametrize("parts", ["1", "3", "64"])
+def test_parts_per_pair(parts, monkeypatch):
+    """A pair's levels spread over several workgroups (level counter in HBM, write-through stores): same layers."""
+    from oracle import oracle
+    from test_gpu_parity import gpu_solve
+    monkeypatch.setenv("BIALIGN_WIDE_PARTS", parts)
+    n, m, s = 70, 64, 6
+    sa, sb, ta, tb = synth.protein_pair(3300, n, m)
+    params = dict(synth.PROTEIN_PARAMS, max_shift=s)
+    ref = oracle.solve(sa, sb, ta, tb, params)
+    got = gpu_solve(dict(seqA=sa, seqB=sb, strA=ta, strB=tb, params=params), layers=True)
+    assert got["score"] == ref["score"] and got["trace"] == oracle.trace_to_lists(ref["trace"])
+    for g, e in zip(oracle.band_values(got["layers"], n, m, s), oracle.band_values(ref["layers"], n, m, s)):
+        np.testing.assert_array_equal(g, e)
+    assert got["timing"]["cross_cu"] == (parts != "1")
+
+
+def test_lost_co_residency_is_recovered(monkeypatch):
+    """Spin limit zero: the level barrier gives up at once; the run is repeated with one workgroup per pair."""
+    from oracle import oracle
+    from bialign_amd.batch import make_batch
+    from bialign_amd.engine import trace_codes_to_columns
+    monkeypatch.setenv("BIALIGN_XCU_SPIN_LIMIT", "0")
+    params = dict(synth.PROTEIN_PARAMS, max_shift=7, gap_opening_cost=0, gap_cost=-200, shift_cost=-250)
+    pairs = [synth.protein_pair(3400 + t, 50 + t, 60) for t in range(3)]
+    for p in (params, dict(synth.PROTEIN_PARAMS, max_shift=6)):
+        b = make_batch(pairs, p)
+        b.run()
+        t = b.timing()
+        assert t["recovered_runs"] == 1 and not t["cross_cu"]
+        scores = b.scores()
+        traces, ok = b.traces()
+        b.close()
+        for k, pair in enumerate(pairs):
+            ref = oracle.solve(*pair, p)
+            assert int(scores[k]) == ref["score"]
+            assert trace_codes_to_columns(traces[k], as_tuples=(p["gap_opening_cost"] == 0)) == \
+                (oracle.trace_to_lists(ref["trace"]) if p["gap_opening_cost"] else [tuple(c) for c in oracle.trace_to_lists(ref["trace"])])
+
+
 def test_reduced_storage_is_refused_beyond_the_tiled_band():
     from bialign_amd import _lib
     from bialign_amd.batch import make_batch
