@@ -54,7 +54,7 @@ TeamShape team_shape(const bialign_batch* b, int first, int count, int xcu_resid
   while (tw > 1 && lds_of(tw) > 160 * 1024) tw >>= 1;
   if (b->dense) tw = std::min(tw, b->affine ? 4 : 2);  // dense-mu2 kernels: up to 4 waves (affine), 2 (one layer) per workgroup
   // cross-CU teams (affine LOOKUP kernels only) take any size: the team is a runtime value there
-  int gw = ((b->affine ? (b->S <= 3 || !b->dense) : !b->dense) && xcu_resident > 0) ? fit_exact : 1;
+  int gw = ((!b->affine || b->S <= 3 || !b->dense) && xcu_resident > 0) ? fit_exact : 1;  // (dense affine kernels: s <= 3)
   gw = std::max(1, std::min(gw, xcu_resident / std::max(count, 1)));
   // ... and, for the s=2 sweep, teams of eight-wave workgroups (one per CU, two waves per SIMD)
   int gw8 = (diet8 && xcu8_resident > 0) ? std::min(fit_exact / 8, xcu8_resident / std::max(count, 1)) : 0;

@@ -407,12 +407,12 @@ int launch_fill_linear_t(bialign_batch* b, const DeviceBatch& v, int first, int 
 }
 
 // one-wave workgroups of the one-layer cross-CU kernel the device holds at once
-template <int S, bool LEAN>
+template <int S, bool LEAN, bool DENSE = false>
 int xcu_resident_linear(bialign_batch* b) {
   int& cached = b->xcu_resident[LEAN ? 1 : 0];
   if (cached >= 0) return cached;
   cached = 0;
-  auto kern = fill_linear_kernel<S, 1, false, LEAN, false, true>;
+  auto kern = fill_linear_kernel<S, 1, DENSE, LEAN, false, true>;
   const size_t lds = b->lds_base + b->lds_per_wave;
   if (lds > 64 * 1024 &&
       hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
@@ -429,12 +429,15 @@ int xcu_resident_linear(bialign_batch* b) {
 
 template <int S, bool LEAN>
 int launch_fill_linear_l(bialign_batch* b, const DeviceBatch& v, int first, int count) {
-  const bool xcu_ok = !b->dense && !b->no_xcu;
-  const TeamShape ts = team_shape(b, first, count, xcu_ok ? xcu_resident_linear<S, LEAN>(b) : 0);
+  const bool xcu_ok = !b->no_xcu;
+  const TeamShape ts = team_shape(b, first, count, !xcu_ok ? 0 : (b->dense ? xcu_resident_linear<S, LEAN, true>(b)
+                                                                             : xcu_resident_linear<S, LEAN>(b)));
   b->last_team = ts.waves() * (ts.gw > 1 ? -1 : 1);
-  if (b->dense)
+  if (b->dense) {
+    if (ts.gw > 1) return launch_fill_linear_t<S, 1, true, LEAN, true>(b, v, first, count, ts.gw);
     return ts.tw >= 2 ? launch_fill_linear_t<S, 2, true, LEAN>(b, v, first, count)
                       : launch_fill_linear_t<S, 1, true, LEAN>(b, v, first, count);
+  }
   if (ts.gw > 1) return launch_fill_linear_t<S, 1, false, LEAN, true>(b, v, first, count, ts.gw);
   switch (ts.tw) {
     case 8: return launch_fill_linear_t<S, 8, false, LEAN>(b, v, first, count);

@@ -93,7 +93,7 @@ LIN = dict(gap_opening_cost=0, gap_cost=-200, shift_cost=-250)
     (150, 400, 2, 70, {}, "2"), (257, 129, 1, 71, dict(gap_opening_cost=100), None),
     (130, 75, 1, 72, LIN, None), (75, 130, 2, 73, LIN, None), (120, 110, 0, 74, LIN, None),
     (50, 60, 3, 75, LIN, None), (33, 45, 5, 76, LIN, None), (300, 320, 1, 77, LIN, "2"),
-    (200, 400, 2, 78, LIN, "2")])
+    (200, 400, 2, 78, LIN, "2"), (330, 650, 1, 79, LIN, "x6"), (200, 500, 2, 80, LIN, "x5")])
 def test_dense_full_layers_vs_oracle(n, m, s, seed, ov, team, monkeypatch):
     """Random integer mu2 tables: every layer cell, score and trace against the oracle; single
     wave and teams of two (the dense form's largest team)."""
@@ -107,7 +107,7 @@ def test_dense_full_layers_vs_oracle(n, m, s, seed, ov, team, monkeypatch):
     ref = oracle_dense(pair, tab, params)
     got = dense_solve([pair], [tab], params, layers_of=0)
     if team:
-        assert got["timing"]["waves_per_pair"] == int(team)
+        assert got["timing"]["waves_per_pair"] == int(team.lstrip("x")) and got["timing"]["cross_cu"] == team.startswith("x")
     assert got["scores"][0] == ref["score"]
     assert got["traces"][0] == oracle.trace_to_lists(ref["trace"])
     assert got["complete"][0] == ref["complete"]
