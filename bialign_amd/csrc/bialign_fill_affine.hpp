@@ -336,6 +336,17 @@ __global__ void __launch_bounds__(64 * TW) fill_affine_kernel(const DeviceBatch 
       }
       prefetch_block(g + GF::BLK, ghalf ^ 1, jj + GF::BLK);
       vm_younger = 0;
+      if (A.prio_mode) {
+        // Issue arbitration favours the oldest wave of a SIMD: the first workgroup dispatched to a CU finishes early
+        // and leaves its SIMD to a lone wave that cannot fill it (round 1 saw first-finish 14.8 ms, last 21.3).  Rotating
+        // four priority levels over the workgroups of a CU by age (blockIdx / 256 CUs) every 128 steps keeps the waves of
+        // a SIMD level: -8 % fill time at len 1024, -5.6 % at config 2, -5 % on config 4 (profiles/r02k_priority).
+        const int lvl = ((g >> 7) + (int)(blockIdx.x >> 8)) & 3;
+        if (lvl == 0) __builtin_amdgcn_s_setprio(0);
+        else if (lvl == 1) __builtin_amdgcn_s_setprio(1);
+        else if (lvl == 2) __builtin_amdgcn_s_setprio(2);
+        else __builtin_amdgcn_s_setprio(3);
+      }
     }
     bool ghost_packed = false;
     if (PACK && !PK_COOP) {  // per step: is the ghost row's source record (phase c + 2(R-1) of the strip above) a packed one?

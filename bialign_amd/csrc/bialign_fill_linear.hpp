@@ -165,6 +165,13 @@ __global__ void __launch_bounds__(64 * TW) fill_linear_kernel(const DeviceBatch 
       if (T > 1 && L == 0) prog_put(g - GF::BLK);  // see the affine kernel
       prefetch_block(g + GF::BLK, ghalf ^ 1, jj + GF::BLK);
       vm_younger = 0;
+      if (A.prio_mode) {  // wave priorities rotate over the workgroups of a CU by age: see fill_affine_kernel
+        const int lvl = ((g >> 7) + (int)(blockIdx.x >> 8)) & 3;
+        if (lvl == 0) __builtin_amdgcn_s_setprio(0);
+        else if (lvl == 1) __builtin_amdgcn_s_setprio(1);
+        else if (lvl == 2) __builtin_amdgcn_s_setprio(2);
+        else __builtin_amdgcn_s_setprio(3);
+      }
     }
     GF::fetch(ghostM, ring + ghalf * GF::SLOTS, gt, aa);
     int inLW[W], inLW1[W], inL1[W];

@@ -165,6 +165,7 @@ struct bialign_batch {
     v.tstate = d_tstate.p;
     v.resw_k = resw_k;
     v.wide_s = S;
+    v.prio_mode = getenv("BIALIGN_PRIO") ? atoi(getenv("BIALIGN_PRIO")) : 1;
     v.spin_limit = 1 << 20;  // waves of one workgroup are co-resident by construction: a timeout there is a bug
     return v;
   }

@@ -51,6 +51,7 @@ struct DeviceBatch {
   TraceState* tstate;   // lean traceback: [npairs]
   int32_t resw_k;       // lean traceback: strips re-swept (in parallel) and walked per round
   int32_t wide_s;       // wide-band path (max_shift beyond the tiled kernels): the band half-width
+  int32_t prio_mode;    // 1 = rotate wave priorities by workgroup age (fill_affine_kernel); BIALIGN_PRIO=0 switches it off
   int32_t spin_limit;   // team hand-off: polls of the partner's progress word before a wave gives up (error flag)
 };
 
