@@ -581,6 +581,36 @@ int bialign_batch_create(bialign_engine* eng, const bialign_params* prm, const b
   b->packed_sizing = b->pack && !b->lean;
   if (int rc = plan_chunks(b.get(), pair_dwords, budget_dw)) return rc;
 
+  // ---- the layer buffer: a cached one if large enough, else a new one; if the device cannot provide a chunk of the
+  //      planned size after all (fragmentation, another tenant), plan smaller chunks and try again
+  size_t layer_dw = 0;
+  for (int attempt = 0;; ++attempt) {
+    layer_dw = (size_t)b->max_chunk_dwords + 16;  // slack: ghost tail pieces are read 16 B wide
+    DevBuf<int32_t>* slot = nullptr;  // the smallest cached buffer that is large enough
+    for (DevBuf<int32_t>* c : {&eng->layer_cache, &eng->layer_cache2})
+      if (c->p && c->n >= layer_dw && (!slot || c->n < slot->n)) slot = c;
+    if (slot) {
+      b->d_layers.swap(*slot);
+      break;
+    }
+    eng->layer_cache.release();
+    eng->layer_cache2.release();
+    hipError_t err = b->d_layers.alloc(layer_dw);
+    if (err == hipSuccess && attempt == 0 && getenv("BIALIGN_TEST_FAIL_ALLOC")) {  // tests: pretend the first allocation failed
+      b->d_layers.release();
+      err = hipErrorOutOfMemory;
+    }
+    if (err == hipSuccess) break;
+    (void)hipGetLastError();
+    b->d_layers.p = nullptr;
+    b->d_layers.n = 0;
+    const int64_t smaller = (int64_t)b->max_chunk_dwords * 3 / 4;
+    if (attempt >= 3 || smaller < *std::max_element(pair_dwords.begin(), pair_dwords.end()))
+      return fail(BIALIGN_E_DEVICE, "hipMalloc of %zu bytes of layer storage failed: %s", layer_dw * 4, hipGetErrorString(err));
+    for (PairDesc& d : b->pairs) d.scratch_off -= d.layer_off, d.layer_off = 0;  // back to pair-relative, as before the first plan
+    if (int rc = plan_chunks(b.get(), pair_dwords, smaller)) return rc;
+  }
+
   // ---- upload (own stream: a batch can be prepared while another one sweeps)
   hipStream_t st = eng->copy_stream;
   HIP_TRY(b->d_pairs.upload(b->pairs.data(), b->pairs.size(), st));
@@ -594,17 +624,6 @@ int bialign_batch_create(bialign_engine* eng, const bialign_params* prm, const b
   HIP_TRY(b->d_seq_b.upload(pr->seq_b, tot_b, st));
   HIP_TRY(b->d_cls_b.upload(b->dense ? zeros.data() : pr->cls_b, tot_b, st));
   if (b->dense) HIP_TRY(b->d_mu2.upload(pr->mu2_dense, (size_t)tot_mu2, st));
-  const size_t layer_dw = (size_t)b->max_chunk_dwords + 16;  // slack: ghost tail pieces are read 16 B wide
-  DevBuf<int32_t>* slot = nullptr;  // the smallest cached buffer that is large enough
-  for (DevBuf<int32_t>* c : {&eng->layer_cache, &eng->layer_cache2})
-    if (c->p && c->n >= layer_dw && (!slot || c->n < slot->n)) slot = c;
-  if (slot) {
-    b->d_layers.swap(*slot);
-  } else {
-    eng->layer_cache.release();
-    eng->layer_cache2.release();
-    HIP_TRY(b->d_layers.alloc(layer_dw));
-  }
   if (getenv("BIALIGN_DEBUG")) {  // placement study: address and plain streaming-write rate of the layer buffer
     float ms = 0;
     for (int rep = 0; rep < 2; ++rep) {

@@ -129,3 +129,26 @@ def test_destroy_order_is_free():
         "f(); print('done')"])
     out = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "done" in out.stdout, out.stderr[-500:]
+
+
+def test_smaller_chunks_when_the_layer_buffer_cannot_be_allocated(monkeypatch):
+    """If hipMalloc refuses the planned chunk (fragmentation, another tenant), the batch is re-planned into smaller
+    chunks instead of failing -- same results."""
+    from bialign_amd.batch import make_batch
+    from bialign_amd.engine import Engine
+    pairs = [synth.protein_pair(2600 + t, 150 + 3 * t, 170) for t in range(8)]
+    params = dict(synth.PROTEIN_PARAMS)
+    eng = Engine(0)
+    ref = make_batch(pairs, params, engine=eng)
+    ref.run()
+    want = (ref.scores().tolist(), [t.tolist() for t in ref.traces()[0]])
+    assert ref.info["nchunks"] == 1
+    ref.close()
+    eng.trim()
+    monkeypatch.setenv("BIALIGN_TEST_FAIL_ALLOC", "1")
+    b = make_batch(pairs, params, engine=eng)
+    assert b.info["nchunks"] >= 2
+    b.run()
+    assert (b.scores().tolist(), [t.tolist() for t in b.traces()[0]]) == want
+    b.close()
+    eng.close()
