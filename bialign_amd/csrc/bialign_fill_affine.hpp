@@ -341,7 +341,7 @@ __global__ void __launch_bounds__(64 * TW) fill_affine_kernel(const DeviceBatch 
         // and leaves its SIMD to a lone wave that cannot fill it (round 1 saw first-finish 14.8 ms, last 21.3).  Rotating
         // four priority levels over the workgroups of a CU by age (blockIdx / 256 CUs) every 128 steps keeps the waves of
         // a SIMD level: -8 % fill time at len 1024, -5.6 % at config 2, -5 % on config 4 (profiles/r02k_priority).
-        const int lvl = ((g >> 7) + (int)(blockIdx.x >> 8) + (A.prio_mode == 2 ? (wl >> 2) : 0)) & 3;
+        const int lvl = ((g >> 7) + (int)(blockIdx.x >> 8)) & 3;
         if (lvl == 0) __builtin_amdgcn_s_setprio(0);
         else if (lvl == 1) __builtin_amdgcn_s_setprio(1);
         else if (lvl == 2) __builtin_amdgcn_s_setprio(2);
