@@ -503,7 +503,10 @@ int bialign_batch_create(bialign_engine* eng, const bialign_params* prm, const b
     const bool force = e && e[0] == '1';
     const PackInfo pki = pack_info(S);
     bool ok = b->affine && S >= 1 && S <= BIALIGN_MAX_SHIFT_PACKED && !b->lean && prm->gap_opening_cost <= 0 && !(e && e[0] == '0') &&
-              (force || colmax < 8192);  // offsets span a few column scores (measured: up to 2.5): beyond this they will not fit
+              (force || colmax < 8192) &&  // offsets span a few column scores (measured: up to 2.5): beyond this they will not fit
+              // s=3 runs one wave per SIMD and is bound by issue: packing pays in big batches (in-workgroup teams, +7 %),
+              // not in the cross-CU teams of a few long pairs (-8 %)
+              (force || S < 3 || pr->npairs >= 128);
     for (int p = 0; ok && p < pr->npairs; ++p) {
       const PairDesc& d = b->pairs[p];
       const int interior = d.m - S - pki.lo + 1;  // phases LO .. m - S per strip

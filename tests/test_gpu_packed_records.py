@@ -42,17 +42,22 @@ def check(pair, params, expect_packed=True):
 
 @pytest.mark.parametrize("n,m,s,seed", [(150, 160, 1, 1), (70, 300, 1, 2), (300, 170, 1, 3), (400, 400, 1, 10),
                                          (64, 140, 2, 6), (130, 131, 2, 7), (250, 120, 2, 9), (90, 150, 3, 11), (40, 200, 3, 12)])
-def test_default_policy_full_layers(n, m, s, seed):
-    """Shapes the engine packs by itself (a quarter of the bytes saved)."""
+def test_default_policy_full_layers(n, m, s, seed, monkeypatch):
+    """Shapes the engine packs by itself (a fifth of the bytes saved; s=3 only in batches of 128 pairs and more, so
+    forced here)."""
+    if s == 3:
+        monkeypatch.setenv("BIALIGN_PACK", "1")
     check(synth.protein_pair(4000 + seed, n, m), dict(synth.PROTEIN_PARAMS, max_shift=s))
 
 
 @pytest.mark.parametrize("seed", range(6))
-def test_odd_valued_scores_stay_packed(seed):
+def test_odd_valued_scores_stay_packed(seed, monkeypatch):
     """Scores with all kinds of low bits (the OR of a lane's offsets may then be 0xffff without any offset being out of
     range): packed, no repeat, every cell equal to the oracle."""
     rng = np.random.default_rng(900 + seed)
     s = 1 + seed % 3
+    if s == 3:
+        monkeypatch.setenv("BIALIGN_PACK", "1")
     params = dict(synth.PROTEIN_PARAMS, max_shift=s, simmatrix=None, sequence_match_similarity=int(rng.integers(50, 999)),
                   sequence_mismatch_similarity=-int(rng.integers(1, 499)), structure_weight=int(rng.integers(1, 1111)),
                   gap_opening_cost=-int(rng.integers(1, 333)), gap_cost=-int(rng.integers(1, 277)),
@@ -78,6 +83,8 @@ def test_forced_on_short_pairs(n, m, s, seed, monkeypatch):
                                         ("h2", 360, 810, 2), ("4", 80, 300, 3), ("x4", 90, 400, 3)])
 def test_team_shapes(team, n, m, s, monkeypatch):
     monkeypatch.setenv("BIALIGN_TEAM", team)
+    if s == 3:
+        monkeypatch.setenv("BIALIGN_PACK", "1")
     got = check(synth.protein_pair(4200 + n, n, m), dict(synth.PROTEIN_PARAMS, max_shift=s))
     assert got["timing"]["waves_per_pair"] == (8 * int(team[1:]) if team[0] == "h" else int(team.lstrip("x")))
 
@@ -91,11 +98,13 @@ def test_rna_and_golden_cases():
 
 
 @pytest.mark.parametrize("s", [1, 2, 3])
-def test_dense_mu2_packed(s):
+def test_dense_mu2_packed(s, monkeypatch):
     """DENSE mu2 (per-pair int32 tables, the predicted-structure RNA form) with packed records: full layers vs oracle."""
     from oracle import oracle
     from bialign_amd.batch import make_batch
     from bialign_amd.engine import trace_codes_to_columns
+    if s == 3:
+        monkeypatch.setenv("BIALIGN_PACK", "1")
     rng = np.random.default_rng(50 + s)
     shapes = [(150, 170), (170, 220)]
     pairs = [synth.rna_pair(4700 + t, n, m) for t, (n, m) in enumerate(shapes)]
@@ -197,6 +206,16 @@ def test_fallback_replans_a_chunked_batch(monkeypatch):
         assert int(scores[k]) == ref["score"]
         assert trace_codes_to_columns(traces[k]) == oracle.trace_to_lists(ref["trace"])
         assert bool(ok[k]) == ref["complete"]
+
+
+def test_s3_policy_by_batch_size():
+    from bialign_amd.batch import make_batch
+    params = dict(synth.PROTEIN_PARAMS, max_shift=3)
+    for npairs, expect in ((4, False), (130, True)):
+        b = make_batch(synth.protein_batch(npairs, 150, seed0=5000), params)
+        b.run()
+        assert b.timing()["packed_records"] == expect
+        b.close()
 
 
 def test_batch_of_1024_len_512_properties():
