@@ -96,13 +96,14 @@ TeamShape team_shape(const bialign_batch* b, int first, int count, int xcu_resid
   int t = 1;
   while (t < tw && concurrent(t) * 100 < best * 95) t *= (skip2 && t == 1) ? 4 : 2;
   ts.tw = t;
-  // cross-CU: when the chip would stay mostly empty and the team can be at least doubled -- or, for
-  // a handful of pairs, not doubled but spread: eight waves on eight CUs beat eight waves sharing
-  // one CU's SIMDs two by two (one 928 x 933 pair: 7.6 vs 9.4 ms)
+  // cross-CU: when that keeps at least 1.4 x the waves running (117 pairs x len 1024: 16 one-wave workgroups per pair
+  // instead of 8 waves in one, 12.9 -> 9.7 ms; 300 x len 512: 6 instead of 4, 7.6 -> 6.7 ms; at equal wave counts the
+  // in-workgroup team wins: 256 x len 1024, 15.4 vs 16.8 ms) -- or, for a handful of pairs, not more waves but spread:
+  // eight waves on eight CUs beat eight waves sharing one CU's SIMDs two by two (one 928 x 933 pair: 7.6 vs 9.4 ms)
   int64_t running = concurrent(t);
-  if (count * t <= 512) {
+  {
     const int g = std::min(gw, std::max(1, 2048 / count));
-    if (g >= 2 * t || (t == 8 && g >= 8 && count * 8 <= b->eng->num_cu)) {
+    if (g >= 2 && ((int64_t)count * g * 10 >= running * 14 || (t == 8 && g >= 8 && count * 8 <= b->eng->num_cu))) {
       ts.tw = 1;
       ts.gw = g;
       running = (int64_t)count * g;
@@ -504,9 +505,9 @@ int bialign_batch_create(bialign_engine* eng, const bialign_params* prm, const b
     const PackInfo pki = pack_info(S);
     bool ok = b->affine && S >= 1 && S <= BIALIGN_MAX_SHIFT_PACKED && !b->lean && prm->gap_opening_cost <= 0 && !(e && e[0] == '0') &&
               (force || colmax < 8192) &&  // offsets span a few column scores (measured: up to 2.5): beyond this they will not fit
-              // s=3 runs one wave per SIMD and is bound by issue: packing pays in big batches (in-workgroup teams, +7 %),
-              // not in the cross-CU teams of a few long pairs (-8 %)
-              (force || S < 3 || pr->npairs >= 128);
+              // s=3 runs one wave per SIMD and is bound by issue: packing pays where the device is full (512 pairs x len 512
+              // +7 %, 86 pairs in cross-CU teams of 11 +25 %), not for a few long pairs (21 x len 1024: -14 %, 8 x len 2048: -15 %)
+              (force || S < 3 || pr->npairs >= 64);
     for (int p = 0; ok && p < pr->npairs; ++p) {
       const PairDesc& d = b->pairs[p];
       const int interior = d.m - S - pki.lo + 1;  // phases LO .. m - S per strip
