@@ -35,10 +35,6 @@ template <bool V>
 struct BoolTag {
   static constexpr bool value = V;
 };
-template <int V>
-struct IntTag {
-  static constexpr int value = V;
-};
 
 // BETA_NONPOS: gap_opening_cost <= 0 (every practical parameter set).  Then
 // open(h,T) + v[h] <= v[T] + ... lets f_X, f_Y reuse f_M's max3:
@@ -55,9 +51,10 @@ struct IntTag {
 //   XCU = false: the team is one workgroup of TW waves (T = TW), progress words in LDS.
 //   XCU = true : the team is A.team workgroups of TW waves on any CUs / XCDs (T = A.team * TW,
 //     block b -> pair b / A.team, waves (b % A.team) * TW ..; all co-resident by construction of the grid).
-//     Per-XCD L2s are not coherent, so every layer store is write-through (sc1), the ghost
-//     DMAs and the progress words are sc1 accesses too, and a word is published only
-//     after the stores it covers have left the wave's vector-memory queue.
+//     Per-XCD L2s are not coherent, so the layer stores of a wave whose successor runs on another CU are
+//     write-through (sc1) -- every wave of a one-wave workgroup, the last wave of an eight-wave one -- the
+//     ghost DMAs are sc1 loads, the progress words between CUs live in HBM (sc1 atomics), and a word is
+//     published only after the stores it covers have left the wave's vector-memory queue.
 typedef int v3i __attribute__((ext_vector_type(3)));
 
 // wt (wave-uniform): write through to memory -- the records of a wave whose successor runs on another CU
