@@ -590,7 +590,9 @@ __global__ void __launch_bounds__(64 * TW) fill_affine_kernel(const DeviceBatch 
 #pragma unroll
           for (int c = 0; c < PK_::NCH; ++c) {
             const int last = 8 * c + 5 < ND - 1 ? 8 * c + 5 : ND - 1;  // last value of chunk c
-            if (last >= bb * 9 && last < (bb + 1) * 9) {
+            // (issued together after the last point: the packed sweep is bound by issue, not by the store queue -- spreading
+            //  them over the step, which paid 6 % with full records, now costs 1-2.5 %: config-4 chunk 78.5 vs 76.5 ms)
+            if ((BIALIGN_OPT & 4) ? bb == W - 1 : (last >= bb * 9 && last < (bb + 1) * 9)) {
               int dw[4];
 #pragma unroll
               for (int x = 0; x < 4; ++x) {

@@ -45,8 +45,8 @@
 #ifndef BIALIGN_PADMAX
 #define BIALIGN_PADMAX 2
 #endif
-#ifndef BIALIGN_OPT  // A/B switches of equivalent step code: 1 = fused DPP-min exchange, 2 = ghost rows by branch
-#define BIALIGN_OPT 3
+#ifndef BIALIGN_OPT  // A/B switches of equivalent step code: 1 = fused DPP-min exchange, 2 = ghost rows by branch,
+#define BIALIGN_OPT 7  // 4 = packed records: all of a step's stores after its last point (one exec region instead of NCH)
 #endif
 
 #include "bialign_types.hpp"
