@@ -7,13 +7,18 @@ gathered) over one rank's batch of synthetic pairs, inputs resident in HBM.
 Workload = what BASELINE.json's metric is quoted on: **1024 synthetic protein
 pairs per GPU, n = m = 1024, BLOSUM62, affine gaps, max_shift = 1** -- config 5's
 per-GPU share (rank r owns pairs [r*1024, (r+1)*1024), pair p
-is drawn from seed 1000 + p).  Its nine int32 layers are 348 GB, so one step is
-two chunks (fill -> traceback -> fill -> traceback) through one 174 GB buffer.
+is drawn from seed 1000 + p).  Its nine int32 layers are 348 GB; with packed
+layer records (233 GB in HBM) one step is ONE fill launch + one traceback launch.
 Pairs are independent: ranks share nothing on the data path, the only collective
 is the final all_gather of int32 scores over RCCL (weak scaling).
 
     python bench.py [--gpus N --steps K --warmup W]
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+``python bench.py --gpus N`` (N > 1) outside torchrun starts its own N rank
+processes: a child ``python -m torch.distributed.run --nproc-per-node N bench.py ...``
+launched before this process has touched torch or the GPU; the parent relays
+rank 0's JSON line and the child's exit code.
 
 Prints ONE JSON line on rank 0.  At N=1 the line also carries
 `cpu_baseline` (the C oracle on one host core and on all host cores of this box,
@@ -42,9 +47,9 @@ def _oracle_pair(job):
     p = dict(synth.PROTEIN_PARAMS, max_shift=s)
     mu1, mu2 = oracle.mu_tables(sa, sb, ta, tb, p)  # input preparation, not timed
     t0 = time.perf_counter()
-    _, layers = oracle.affine_fill(length, length, s, p["gap_opening_cost"], p["gap_cost"], p["shift_cost"], mu1, mu2)
+    score, layers = oracle.affine_fill(length, length, s, p["gap_opening_cost"], p["gap_cost"], p["shift_cost"], mu1, mu2)
     oracle.affine_traceback(length, length, s, p["gap_opening_cost"], p["gap_cost"], p["shift_cost"], mu1, mu2, layers)
-    return time.perf_counter() - t0, synth.cells_per_pair(length, length, s)
+    return time.perf_counter() - t0, synth.cells_per_pair(length, length, s), int(score)
 
 
 def cpu_baseline(length, s, seed0, budget_s=12.0):
@@ -54,11 +59,12 @@ def cpu_baseline(length, s, seed0, budget_s=12.0):
     import multiprocessing as mp
     from oracle import oracle
     oracle.build()
-    spent, cells, n1 = 0.0, 0, 0
+    spent, cells, n1, scores = 0.0, 0, 0, []
     while spent < budget_s and n1 < 8:
-        dt, c = _oracle_pair((seed0 + n1, length, s))
+        dt, c, sc = _oracle_pair((seed0 + n1, length, s))
         spent += dt
         cells += c
+        scores.append(sc)  # kept: the GPU's scores of the same pairs are compared with them after the timed region
         n1 += 1
     one = cells / spent / 1e9
     cores = min(len(os.sched_getaffinity(0)), int(os.environ.get("CPU_SHARE", 16)))
@@ -68,9 +74,9 @@ def cpu_baseline(length, s, seed0, budget_s=12.0):
     with mp.get_context("fork").Pool(cores) as pool:
         res = pool.map(_oracle_pair, jobs, chunksize=1)
     wall = time.perf_counter() - t0
-    return {"value": one, "unit": "Gcells/s", "cores": 1, "kind": "port",
+    return {"value": one, "unit": "Gcells/s", "cores": 1, "kind": "port", "_scores": scores,
             "sample": f"first {n1} pairs of the workload (fill+traceback, {cells} cells, {spent:.1f} s on one host core)",
-            "all_cores": {"value": sum(c for _, c in res) / wall / 1e9, "unit": "Gcells/s", "cores": cores,
+            "all_cores": {"value": sum(r[1] for r in res) / wall / 1e9, "unit": "Gcells/s", "cores": cores,
                           "sample": f"first {len(jobs)} pairs, one process per core, {wall:.1f} s wall"},
             # the Cython reference itself cannot travel to this box; its rate was measured in the dev container
             "reference_cython": {"value": 21e-6, "unit": "Gcells/s", "cores": 1, "measured_live": False,
@@ -89,19 +95,85 @@ def run_steps(batch, count, gather, npairs_total):
 
 
 def roofline(info, fill_ms, launches, key):
+    """`achieved` = ALGORITHMIC bytes (36 B per DP cell) of one fill launch / its average
+    duration (HIP events on the engine's stream).  Beside it, from the committed rocprofv3 counter passes of the same
+    launch shape (profiles/hbm_traffic.json names the directory): `traffic` = FETCH_SIZE + WRITE_SIZE bytes per launch,
+    `traffic_frac` = that / launch time / 8 TB/s (what the memory system really moves), `issue` = VALU
+    wave-instructions x 2 cycles (a wave64 VALU instruction occupies a SIMD-32 for two) / (SIMDs x clock x launch
+    time); `bound` names the largest of the three fractions."""
     fill_avg_ms = fill_ms / max(launches, 1)                  # average fill-kernel launch
     bytes_per_launch = info["layer_bytes"] / info["nchunks"]  # 36 B x cells of one launch
     achieved = bytes_per_launch / (fill_avg_ms * 1e-3) / 1e9
-    traffic, source = None, None
+    out = {"bound": "hbm", "kernel": "fill_affine_kernel", "achieved": achieved, "peak": HBM_PEAK_GBPS,
+           "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None, "traffic_source": None,
+           "bytes_per_launch": bytes_per_launch, "avg_launch_ms": fill_avg_ms}
     tpath = os.path.join(REPO, "profiles", "hbm_traffic.json")
-    if os.path.exists(tpath):  # PMC counters cannot be read from inside the run: per-launch bytes of the same
+    if os.path.exists(tpath):  # PMC counters cannot be read from inside the run: per-launch values of the same
         with open(tpath) as fh:  # launch shape from the committed rocprofv3 passes, with their directory
             entry = json.load(fh).get(key)
         if entry:
-            traffic, source = entry["bytes_per_launch"], entry["profile"]
-    return {"bound": "hbm", "kernel": "fill_affine_kernel", "achieved": achieved, "peak": HBM_PEAK_GBPS,
-            "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": source,
-            "bytes_per_launch": bytes_per_launch, "avg_launch_ms": fill_avg_ms}
+            out["traffic"], out["traffic_source"] = entry["bytes_per_launch"], entry["profile"]
+            out["traffic_frac"] = entry["bytes_per_launch"] / (fill_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS
+            if entry.get("valu_wave_insts_per_launch"):
+                simds, clock = 1024, entry.get("clock_ghz", 2.4) * 1e9
+                out["issue"] = entry["valu_wave_insts_per_launch"] * 2 / (simds * clock * fill_avg_ms * 1e-3)
+                out["issue_source"] = f"SQ_INSTS_VALU {entry['valu_wave_insts_per_launch']:.4g} per launch, " \
+                                      f"clock {entry.get('clock_ghz', 2.4)} GHz ({entry['profile']})"
+            fr = {"hbm (algorithmic bytes)": out["frac"], "hbm (measured traffic)": out["traffic_frac"],
+                  "valu issue": out.get("issue", 0.0)}
+            out["bound_detail"] = max(fr, key=fr.get)
+    return out
+
+
+def self_launch(args, argv):
+    """`python bench.py --gpus N` outside torchrun: start the N rank processes as a CHILD (never an exec, and before
+    this process has imported torch or touched the GPU), relay rank 0's JSON line and the child's exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for out in proc.stdout:  # the ranks' stderr passes through; of stdout only the JSON line is ours
+        try:
+            if "metric" in json.loads(out):
+                line = out.strip()
+                continue
+        except ValueError:
+            pass
+        sys.stderr.write(out)
+    rc = proc.wait()
+    if line:
+        print(line, flush=True)
+    raise SystemExit(rc if rc else (0 if line else 1))
+
+
+class DryBatch:
+    """BIALIGN_BENCH_REHEARSE=dry: the launch / shard / gather / timing plumbing with NO engine behind it (a box
+    without a GPU: the non-GPU test of the N > 1 flow).  Its "scores" are the global pair indices, so the gather's
+    block layout can be checked; nothing is measured."""
+    def __init__(self, first, count, length, s):
+        from bialign_amd import synth
+        import numpy as np
+        self._scores = np.arange(first, first + count, dtype=np.int32)
+        cells = synth.cells_per_pair(length, length, s) * count
+        self.info = {"cells": cells, "npairs": count, "nchunks": 1, "layer_bytes": 36 * cells, "hbm_layer_bytes": 0}
+
+    def run(self):
+        pass
+
+    def scores(self):
+        return self._scores
+
+    def timing(self):
+        return {"fill_ms": 1.0, "traceback_ms": 0.0, "fill_launches": 1, "waves_per_pair": 0, "packed_records": 0}
+
+    def close(self):
+        pass
 
 
 def main():
@@ -119,23 +191,30 @@ def main():
                          "needs twice the buffer in free HBM, i.e. not possible at the default workload")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args, sys.argv[1:])  # does not return
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    # BIALIGN_BENCH_REHEARSE: rehearse the N>1 flow on a box with fewer GPUs than ranks -- for testing the script,
+    # never for numbers.  "1": ranks share the GPU(s), collectives over gloo;  "dry": no GPU at all (DryBatch).
+    rehearse = os.environ.get("BIALIGN_BENCH_REHEARSE", "") in ("1", "dry")
+    dry = os.environ.get("BIALIGN_BENCH_REHEARSE") == "dry"
 
     cpu = None
-    if world == 1 and not args.no_cpu_baseline:  # host cores only, before the GPU is initialised
+    if world == 1 and not args.no_cpu_baseline and not dry:  # host cores only, before the GPU is initialised
         cpu = cpu_baseline(args.length, args.max_shift, 1000)
 
+    import numpy as np
     import torch
     import torch.distributed as dist
-    # BIALIGN_BENCH_REHEARSE=1: rehearse the N>1 flow on a box with fewer GPUs than ranks
-    # (ranks share devices, collectives over gloo) -- for testing the script, never for numbers.
-    rehearse = os.environ.get("BIALIGN_BENCH_REHEARSE") == "1"
-    device = local_rank % torch.cuda.device_count() if rehearse else local_rank
-    torch.cuda.set_device(device)
+    device = 0
+    if not dry:
+        device = local_rank % torch.cuda.device_count() if rehearse else local_rank
+        torch.cuda.set_device(device)
     cdev = torch.device("cpu") if rehearse else torch.device("cuda", device)  # where collectives run
     if world > 1:
         if rehearse:
@@ -144,26 +223,31 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", device))
 
     from bialign_amd import synth
-    from bialign_amd.batch import make_batch
     from bialign_amd.distributed import gather_scores
-    from bialign_amd.engine import Engine
 
     params = dict(synth.PROTEIN_PARAMS, max_shift=args.max_shift)
-    pairs = synth.protein_batch(args.pairs, args.length, seed0=1000 + rank * args.pairs)
-    engine = Engine(device)
-    budget = 0
-    if rehearse:  # ranks share one GPU's memory
-        budget = int(torch.cuda.mem_get_info(device)[0] * 0.8 / world)
+    seed0 = 1000 + rank * args.pairs
     placement = {"reserve_tries": 1, "probe_gbps": None}
-    if args.reserve_tries > 1 and not rehearse:
-        probe = make_batch(pairs, params, engine=engine)
-        need = probe.info["hbm_layer_bytes"] + 64
-        probe.close()
-        try:
-            placement = {"reserve_tries": args.reserve_tries, "probe_gbps": engine.reserve(need, tries=args.reserve_tries)}
-        except Exception as e:  # placement is an optimisation: never fail the run over it
-            placement["reserve_error"] = str(e)[:200]
-    batch = make_batch(pairs, params, engine=engine, hbm_budget_bytes=budget)  # inputs now resident in HBM
+    engine = None
+    if dry:
+        batch = DryBatch(rank * args.pairs, args.pairs, args.length, args.max_shift)
+    else:
+        from bialign_amd.batch import make_batch
+        from bialign_amd.engine import Engine
+        pairs = synth.protein_batch(args.pairs, args.length, seed0=seed0)
+        engine = Engine(device)
+        budget = 0
+        if rehearse:  # ranks share one GPU's memory
+            budget = int(torch.cuda.mem_get_info(device)[0] * 0.8 / world)
+        if args.reserve_tries > 1 and not rehearse:
+            probe = make_batch(pairs, params, engine=engine)
+            need = probe.info["hbm_layer_bytes"] + 64
+            probe.close()
+            try:
+                placement = {"reserve_tries": args.reserve_tries, "probe_gbps": engine.reserve(need, tries=args.reserve_tries)}
+            except Exception as e:  # placement is an optimisation: never fail the run over it
+                placement["reserve_error"] = str(e)[:200]
+        batch = make_batch(pairs, params, engine=engine, hbm_budget_bytes=budget)  # inputs now resident in HBM
     info = batch.info
     for _ in range(2):  # engine warm-up, not steps: the first launches load the code objects, touch the buffer's pages
         batch.run()     # for the first time and ramp the clocks
@@ -171,7 +255,8 @@ def main():
     def barrier():
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        if not dry:
+            torch.cuda.synchronize()
 
     run_steps(batch, args.warmup, gather_scores, args.pairs * world)
     barrier()
@@ -189,6 +274,19 @@ def main():
     else:
         total_cells, total_pairs = info["cells"], info["npairs"]
     timing = batch.timing()
+    # ---- outside the timed region: what was timed is checked.  Every rank's gathered score vector must hold its own
+    # scores in its block (the gather's layout); rank 0's first pairs are the ones the CPU oracle solved for
+    # `cpu_baseline` -- the GPU's scores of the same pairs must equal them.
+    gathered = gather_scores(batch.scores(), args.pairs * world)
+    own_ok = bool(np.array_equal(gathered[rank * args.pairs:(rank + 1) * args.pairs], batch.scores()))
+    checked = {"gather_layout_ok": own_ok, "gathered_pairs": int(len(gathered))}
+    if dry:
+        checked["gather_layout_ok"] = own_ok and bool(np.array_equal(gathered, np.arange(args.pairs * world)))
+    if cpu is not None:
+        want = cpu.pop("_scores")
+        got = [int(x) for x in batch.scores()[:len(want)]]
+        checked.update({"pairs": len(want), "scores_equal": got == want, "oracle_scores": want, "gpu_scores": got,
+                        "against": "oracle/bialign_oracle.c on the cpu_baseline pairs (seeds 1000..)"})
     batch.close()
 
     line = None
@@ -196,14 +294,15 @@ def main():
         value = total_cells * args.steps / elapsed / 1e9
         is_cfg5 = (args.pairs, args.length, args.max_shift) == (1024, 1024, 1)
         line = {
-            "metric": "giga-DP-cells/sec", "value": value,
+            "metric": "giga-DP-cells/sec", "value": None if dry else value,
             "unit": "Gcells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            **({"rehearsal": "ranks share GPUs, gloo collectives: NOT a measurement"} if rehearse else {}),
+            **({"rehearsal": ("no engine, no GPU (DryBatch): launch/shard/gather plumbing only" if dry else
+                              "ranks share GPUs, gloo collectives") + ": NOT a measurement"} if rehearse else {}),
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "int32", "data": "synthetic",
             "pairs_per_s": total_pairs * args.steps / elapsed,
             # the layer buffer of the headline is whatever hipMalloc returned (no placement probing)
-            **({"value_default_alloc": value} if placement["probe_gbps"] is None else {}),
+            **({"value_default_alloc": value} if placement["probe_gbps"] is None and not dry else {}),
             "config": {"baseline_config": "BASELINE.json configs[4] per-GPU share (the metric's 1k x 1k, max_shift=1 workload)"
                                           if is_cfg5 else "custom (--pairs/--len/--max_shift)",
                        "workload": f"{args.pairs} synthetic protein pairs per GPU, len {args.length}, "
@@ -219,12 +318,14 @@ def main():
                                    f"no data-path collective, one all_gather of int32 scores",
                        "layer_buffer_placement": placement},
             "kernel_ms": {"fill": fill_ms / args.steps, "traceback": tb_ms / args.steps},
-            "roofline": roofline(info, fill_ms, launches, f"protein_{args.pairs}x{args.length}_s{args.max_shift}"),
+            "roofline": None if dry else roofline(info, fill_ms, launches, f"protein_{args.pairs}x{args.length}_s{args.max_shift}"),
+            "checked": checked,
         }
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu  # measured at N=1 only (None otherwise)
 
     if rank == 0 and world == 1 and not args.no_extra and not rehearse:
+        from bialign_amd.batch import make_batch
         # ---- untimed extra: BASELINE configs[1] (1024 pairs x len 512), first on the buffer the engine
         # already holds (default allocation), then on a placement-probed one (profiles/r01e_placement)
         c2pairs = synth.protein_batch(1024, 512, seed0=1000)
@@ -257,9 +358,14 @@ def main():
 
     if rank == 0:
         print(json.dumps(line), flush=True)
-    engine.close()
+    if engine is not None:
+        engine.close()
     if world > 1:
         dist.destroy_process_group()
+    if rank == 0 and not checked.get("scores_equal", True):
+        raise SystemExit("bench: GPU scores differ from the oracle's on the checked pairs")
+    if not checked["gather_layout_ok"]:
+        raise SystemExit("bench: gathered scores do not match this rank's own block")
 
 
 if __name__ == "__main__":

@@ -279,6 +279,48 @@ __global__ void __launch_bounds__(64 * TW) fill_affine_kernel(const DeviceBatch 
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   int vm_younger = 0;  // store instructions issued since the last block's DMAs (wave-uniform)
 
+  // Exchange inputs of rows i-1 (what lanes L-W, L-W+1 published for each band column).  BIALIGN_OPT & 8: they are
+  // loop-carried -- row r is fetched from the exchange array at the END of a step, as soon as its last consumer of
+  // that step is through, for the step after it: the LDS round trip (publish -> read) overlaps the rest of the step
+  // instead of standing at the head of the next one.  Likewise (BIALIGN_OPT & 16) the score inputs of the next
+  // column: the two dependent LDS reads (code byte, then table entry) leave the head of the step.
+  int inA[W][4], inB[W][8];
+  auto read_lds = [&](int r) __attribute__((always_inline)) {
+#pragma unroll
+    for (int x = 0; x < 4; ++x) inA[r][x] = xch[(r * XR + x) * NCOL + colLW];
+#pragma unroll
+    for (int x = 0; x < 8; ++x) inB[r][x] = xch[(r * XR + 4 + x) * NCOL + colLW1];
+  };
+  // A delay-line stage.  With the loop-carried exchange inputs the copy is opaque to the compiler: coalescing it
+  // would keep the old value alive in the register the next fetch wants, and the allocator then copies the freshly
+  // fetched values at the back-edge instead -- behind an lgkmcnt wait, which is the stall the early fetch was to hide.
+  auto dmov = [](int& dst, int src) __attribute__((always_inline)) {
+    if (BIALIGN_OPT & 8) asm("v_mov_b32 %0, %1" : "=v"(dst) : "v"(src));
+    else dst = src;
+  };
+  int mu1n = 0, mu2n[W];
+  auto lookup_mu = [&]() __attribute__((always_inline)) {  // score inputs of the column this lane works on next (LOOKUP form)
+    const int jc = min(max(jj, 0), m + 1);
+    mu1n = s1[s1row + sb[jc - 1 + PADB]];
+#pragma unroll
+    for (int bb = 0; bb < W; ++bb) mu2n[bb] = DENSE ? 0 : s2[s2row + cb[jc + bb]];  // l-1+PADB = jc+bb
+  };
+  if (BIALIGN_OPT & 8) {
+#pragma unroll
+    for (int r = 0; r < W; ++r) read_lds(r);
+  }
+  // ... and, one step further ahead, the two codes an interior step's end looks up (column jj + 1 of the same row)
+  int sbn = 0, cbn = 0;
+  auto fetch_codes = [&]() __attribute__((always_inline)) {
+    const int jc1 = min(max(jj + 1, 0), m + 1);
+    sbn = sb[jc1 - 1 + PADB];
+    cbn = DENSE ? 0 : cb[jc1 + W - 1];
+  };
+  if (BIALIGN_OPT & 16) {
+    lookup_mu();
+    fetch_codes();
+  }
+
   // One step of the sweep.  INTERIOR steps (every lane's lattice points have all
   // four coordinates >= 1 and lie inside the molecule columns; ~90 % of the
   // steps) know that only the band can invalidate a case, so the "no valid case"
@@ -369,12 +411,9 @@ __global__ void __launch_bounds__(64 * TW) fill_affine_kernel(const DeviceBatch 
     // ---- 1. exchange reads: what the three source lanes published last step.  Rows of band
     //         column r are first needed by point r-1, so they are fetched two points ahead
     //         (all of them up front for W <= 3): a sliding window keeps registers flat in W.
-    int inA[W][4], inB[W][8], inC[W][8];
+    int inC[W][8];
     auto read_rows = [&](int r) __attribute__((always_inline)) {
-#pragma unroll
-      for (int x = 0; x < 4; ++x) inA[r][x] = xch[(r * XR + x) * NCOL + colLW];
-#pragma unroll
-      for (int x = 0; x < 8; ++x) inB[r][x] = xch[(r * XR + 4 + x) * NCOL + colLW1];
+      if (!(BIALIGN_OPT & 8)) read_lds(r);
       // lane L-1 = (i, a-1) hands its values over in registers: one DPP wave shift fused with a min
       // against the lane's cap (the sentinel where a-1 leaves the band, INT_MAX elsewhere).  One asm
       // block per band column: the compiler's own DPP folding gives up once the consumers are sunk
@@ -421,7 +460,7 @@ __global__ void __launch_bounds__(64 * TW) fill_affine_kernel(const DeviceBatch 
 
     // ---- 2. score inputs of this column (pyx:260-261; LOOKUP form)
     const int jc = INTERIOR ? jj : min(max(jj, 0), m + 1);
-    const int mu1 = s1[s1row + sb[jc - 1 + PADB]];
+    const int mu1 = (BIALIGN_OPT & 16) ? mu1n : s1[s1row + sb[jc - 1 + PADB]];
     int mu2[W];
     if (DENSE) {  // slide the window, take this step's new value from the ring
 #pragma unroll
@@ -429,6 +468,9 @@ __global__ void __launch_bounds__(64 * TW) fill_affine_kernel(const DeviceBatch 
       mu2w[W - 1] = mu2ring[(ghalf * MF::BLK + gt) * 64 + L];
 #pragma unroll
       for (int bb = 0; bb < W; ++bb) mu2[bb] = mu2w[bb];
+    } else if (BIALIGN_OPT & 16) {
+#pragma unroll
+      for (int bb = 0; bb < W; ++bb) mu2[bb] = mu2n[bb];
     } else {
 #pragma unroll
       for (int bb = 0; bb < W; ++bb) mu2[bb] = s2[s2row + cb[jc + bb]];  // l-1+PADB = jc+bb
@@ -712,22 +754,24 @@ __global__ void __launch_bounds__(64 * TW) fill_affine_kernel(const DeviceBatch 
       for (int u = 0; u < 3; ++u) h2y[u] = H2[u][0];
 
       // delay lines: index bb (bb-1 for GXM/GXX) has served its last consumer of this step
-      dA2[0][bb] = dA1[0][bb];
-      dA2[1][bb] = dA1[1][bb];
-      dA1[0][bb] = inA[bb][0];
-      dA1[1][bb] = inA[bb][1];
-      dB[0][bb] = inB[bb][0];
+      dmov(dA2[0][bb], dA1[0][bb]);
+      dmov(dA2[1][bb], dA1[1][bb]);
+      dmov(dA1[0][bb], inA[bb][0]);
+      dmov(dA1[1][bb], inA[bb][1]);
+      dmov(dB[0][bb], inB[bb][0]);
 #pragma unroll
-      for (int v = 0; v < 3; ++v) dB[1 + v][bb] = inB[bb][2 + v];
+      for (int v = 0; v < 3; ++v) dmov(dB[1 + v][bb], inB[bb][2 + v]);
       dC[0][bb] = inC[bb][0];
       dC[1][bb] = inC[bb][1];
       if (bb >= 1) {
-        dAx[0][bb >= 1 ? bb - 1 : 0] = inA[bb >= 1 ? bb - 1 : 0][2];
-        dAx[1][bb >= 1 ? bb - 1 : 0] = inA[bb >= 1 ? bb - 1 : 0][3];
+        dmov(dAx[0][bb >= 1 ? bb - 1 : 0], inA[bb >= 1 ? bb - 1 : 0][2]);
+        dmov(dAx[1][bb >= 1 ? bb - 1 : 0], inA[bb >= 1 ? bb - 1 : 0][3]);
+        if (BIALIGN_OPT & 8) read_lds(bb >= 1 ? bb - 1 : 0);  // row bb-1 has served this step: fetch what it holds for the next
       }
     }
-    dAx[0][W - 1] = inA[W - 1][2];
-    dAx[1][W - 1] = inA[W - 1][3];
+    dmov(dAx[0][W - 1], inA[W - 1][2]);
+    dmov(dAx[1][W - 1], inA[W - 1][3]);
+    if (BIALIGN_OPT & 8) read_lds(W - 1);
 
     // ---- 6. advance
     ++jj;
@@ -736,6 +780,19 @@ __global__ void __launch_bounds__(64 * TW) fill_affine_kernel(const DeviceBatch 
       ++strip;
       rec_base += (T - 1) * P;
       set_row(strip);
+    }
+    if (BIALIGN_OPT & 16) {
+      if (INTERIOR) {  // same row, next column, everything inside the molecule: the window slides by one, and the
+        mu1n = s1[s1row + sbn];  // two codes it needs were fetched at the end of the step before
+        if (!DENSE) {
+#pragma unroll
+          for (int bb = 0; bb + 1 < W; ++bb) dmov(mu2n[bb], mu2[bb + 1]);
+          mu2n[W - 1] = s2[s2row + cbn];
+        }
+      } else {
+        lookup_mu();
+      }
+      fetch_codes();
     }
   };
 

@@ -30,6 +30,26 @@ def init_from_env(backend=None):
     return rank, local_rank, world
 
 
+def block_layout(npairs_total, world, costs=None):
+    """(blocks, width): the contiguous pair range of every rank and the common padded width of the
+    all_gather's per-rank parts (every shard is padded to the widest)."""
+    blocks = [shard(npairs_total, r, world, costs) for r in range(world)]
+    return blocks, max(1, max(len(b) for b in blocks))
+
+
+def assemble_scores(parts, npairs_total, costs=None):
+    """The gathered per-rank parts (rank order, each padded to the common width) -> the int32 score
+    vector in global pair order.  Split out of ``gather_scores`` so that the layout can be checked
+    without N ranks (tests/test_gpu_dropin.py runs config 5's eight shards on one GPU through it)."""
+    blocks, width = block_layout(npairs_total, len(parts), costs)
+    out = np.empty(npairs_total, dtype=np.int32)
+    for blk, part in zip(blocks, parts):
+        part = np.asarray(part, dtype=np.int32)
+        assert len(part) == width
+        out[blk.start:blk.stop] = part[:len(blk)]
+    return out
+
+
 def gather_scores(local_scores, npairs_total, costs=None):
     """All ranks -> the full int32 score vector in global pair order.
 
@@ -42,18 +62,14 @@ def gather_scores(local_scores, npairs_total, costs=None):
         assert len(local) == npairs_total
         return local.copy()
     world, rank = dist.get_world_size(), dist.get_rank()
-    blocks = [shard(npairs_total, r, world, costs) for r in range(world)]
+    blocks, width = block_layout(npairs_total, world, costs)
     assert len(local) == len(blocks[rank])
-    width = max(1, max(len(b) for b in blocks))  # pad every shard to the widest
     dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
     mine = torch.zeros(width, dtype=torch.int32, device=dev)
     mine[:len(local)] = torch.from_numpy(local).to(dev)
     parts = [torch.empty_like(mine) for _ in range(world)]
     dist.all_gather(parts, mine)
-    out = np.empty(npairs_total, dtype=np.int32)
-    for blk, part in zip(blocks, parts):
-        out[blk.start:blk.stop] = part[:len(blk)].cpu().numpy()
-    return out
+    return assemble_scores([p.cpu().numpy() for p in parts], npairs_total, costs)
 
 
 def align_sharded(pairs, params, device=None, hbm_budget_bytes=0, balance=True):

@@ -282,15 +282,81 @@ def test_full_config4():
     assert info["cells"] == 256 * 9999 * 9999
 
 
+def _oracle_job(job):
+    """Worker (spawned: no GPU state): the CPU oracle on one synthetic protein pair -> score, trace columns, flag."""
+    seed, length = job
+    from bialign_amd import synth as sy
+    from oracle import oracle
+    ref = oracle.solve(*sy.protein_pair(seed, length), dict(sy.PROTEIN_PARAMS))
+    return ref["score"], oracle.trace_to_lists(ref["trace"]), ref["complete"]
+
+
+def _oracle_many(jobs):
+    import multiprocessing as mp
+    with mp.get_context("spawn").Pool(min(len(jobs), max(1, min(16, len(os.sched_getaffinity(0)))))) as pool:
+        return pool.map(_oracle_job, jobs, chunksize=1)
+
+
 def test_full_config5_one_gpu_share():
     """BASELINE config 5, one rank's share (1024 of the 8192 protein pairs, len 1024): 348 GB of int32
     layers -- one launch with packed records (233 GB), chunked under a 150 GB budget; rank r of 8 would
-    use seeds 1000 + r*1024 + p."""
+    use seeds 1000 + r*1024 + p.  This is bench.py's own launch shape (packed records, teams of two, every
+    SIMD busy): besides the properties, eight pairs spread over the launch order -- first, last, middle --
+    are compared with the oracle, scores AND traces (the tie-breaks of pyx:535-586 under load)."""
+    from bialign_amd.batch import make_batch
+    from bialign_amd.engine import trace_codes_to_columns
     pairs = synth.protein_batch(1024, 1024)
     info, scores = _full_config_check(pairs, dict(synth.PROTEIN_PARAMS), 16, 0)
     assert info["cells"] == 1024 * 3073 * 3073
     info2, scores2 = _full_config_check(pairs, dict(synth.PROTEIN_PARAMS), 64, 1, hbm_budget_bytes=150 * 10 ** 9)
     np.testing.assert_array_equal(scores, scores2)
+    sample = [0, 1, 255, 511, 512, 777, 1022, 1023]
+    want = _oracle_many([(1000 + p, 1024) for p in sample])
+    b = make_batch(pairs, dict(synth.PROTEIN_PARAMS))
+    b.run()
+    assert b.timing()["packed_records"] == 1 and b.info["nchunks"] == 1 and b.timing()["waves_per_pair"] == 2
+    traces, ok = b.traces()
+    got = b.scores()
+    b.close()
+    np.testing.assert_array_equal(got, scores)
+    for p, (score, cols, complete) in zip(sample, want):
+        assert int(got[p]) == score and bool(ok[p]) == complete, p
+        assert trace_codes_to_columns(traces[p]) == cols, p
+
+
+def test_config5_all_eight_shards_on_one_gpu():
+    """BASELINE config 5 in full -- 8192 protein pairs, len 1024, max_shift 1 -- as its eight rank shards
+    (rank r: seeds 1000 + r*1024 + p, what bench.py gives rank r) run one after the other on this one GPU; the
+    shards' scores go through the all_gather's block layout (distributed.assemble_scores: padded per-rank parts
+    -> global pair order) and two pairs per shard are compared with the oracle."""
+    from bialign_amd.batch import make_batch, shard
+    from bialign_amd.distributed import assemble_scores, block_layout
+    from bialign_amd.engine import Engine
+    params = dict(synth.PROTEIN_PARAMS)
+    world, per = 8, 1024
+    blocks, width = block_layout(world * per, world)
+    assert width == per and [b.start for b in blocks] == [r * per for r in range(world)]
+    sample = [(r, p) for r in range(world) for p in (37 * r % per, per - 1 - 101 * r)]
+    jobs = [(1000 + r * per + p, 1024) for r, p in sample]
+    import multiprocessing as mp
+    pool = mp.get_context("spawn").Pool(min(16, len(os.sched_getaffinity(0))))
+    pending = pool.map_async(_oracle_job, jobs, chunksize=1)   # the host cores work while the GPU sweeps
+    engine = Engine(0)
+    parts = []
+    for r in range(world):
+        assert shard(world * per, r, world) == range(r * per, (r + 1) * per)
+        b = make_batch(synth.protein_batch(per, 1024, seed0=1000 + r * per), params, engine=engine)
+        b.run()
+        assert b.timing()["packed_records"] == 1 and b.info["nchunks"] == 1
+        parts.append(b.scores())
+        b.close()
+    engine.close()
+    allscores = assemble_scores(parts, world * per)
+    assert len(allscores) == 8192 and len(set(allscores[:per].tolist()) - set(allscores[per:2 * per].tolist())) > per // 2
+    want = pending.get(timeout=900)
+    pool.close()
+    for (r, p), (score, _, _) in zip(sample, want):
+        assert int(allscores[r * per + p]) == score, (r, p)
 
 
 def test_long_molecules_large_lds():

@@ -220,5 +220,6 @@ def test_s3_policy_by_batch_size():
 
 def test_batch_of_1024_len_512_properties():
     """BASELINE configs[1] at full size through the packed path: every trace re-scores to its score."""
-    from test_gpu_dropin import _property_check
-    _property_check(synth.protein_batch(96, 512), dict(synth.PROTEIN_PARAMS))
+    from test_gpu_dropin import _full_config_check
+    info, _ = _full_config_check(synth.protein_batch(1024, 512), dict(synth.PROTEIN_PARAMS), 8, 0)  # every 8th trace re-scored
+    assert info["npairs"] == 1024 and info["nchunks"] == 1 and info["cells"] == 1024 * 1537 * 1537
