@@ -52,7 +52,7 @@ def _oracle_pair(job):
     return time.perf_counter() - t0, synth.cells_per_pair(length, length, s), int(score)
 
 
-def cpu_baseline(length, s, seed0, budget_s=12.0):
+def cpu_baseline(length, s, seed0, npairs, budget_s=12.0):
     """oracle/bialign_oracle.c (a literal C port of the reference recurrence, kind "port") on
     the first pairs of the same workload: one host core, then one process per host core of
     this box's share.  Runs before anything touches the GPU (the pool forks)."""
@@ -60,7 +60,7 @@ def cpu_baseline(length, s, seed0, budget_s=12.0):
     from oracle import oracle
     oracle.build()
     spent, cells, n1, scores = 0.0, 0, 0, []
-    while spent < budget_s and n1 < 8:
+    while spent < budget_s and n1 < min(8, npairs):
         dt, c, sc = _oracle_pair((seed0 + n1, length, s))
         spent += dt
         cells += c
@@ -206,7 +206,7 @@ def main():
 
     cpu = None
     if world == 1 and not args.no_cpu_baseline and not dry:  # host cores only, before the GPU is initialised
-        cpu = cpu_baseline(args.length, args.max_shift, 1000)
+        cpu = cpu_baseline(args.length, args.max_shift, 1000, args.pairs)
 
     import numpy as np
     import torch

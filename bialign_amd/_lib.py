@@ -8,9 +8,10 @@ import ctypes
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("BIALIGN_LIB_OVERRIDE") or os.path.join(HERE, "libbialign_hip.so")  # override: timing experiments only
+# override: A/B builds of the engine (tools/exp_build.sh); a timing-experiment build is refused unless asked for by number
+LIB_PATH = os.environ.get("BIALIGN_LIB_OVERRIDE") or os.path.join(HERE, "libbialign_hip.so")
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 RUN_FILL_ONLY = 1
 RUN_ASYNC = 2
 REC_AUTO, REC_AFFINE, REC_LINEAR = 0, 1, 2
@@ -62,6 +63,7 @@ class Timing(ctypes.Structure):
 #: every symbol include/bialign.h declares: (name, restype, argtypes)
 SYMBOLS = [
     ("bialign_abi_version", ctypes.c_int, []),
+    ("bialign_build_experiment", ctypes.c_int, []),
     ("bialign_device_count", ctypes.c_int, []),
     ("bialign_last_error", ctypes.c_char_p, []),
     ("bialign_engine_create", ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]),
@@ -104,6 +106,12 @@ def _load():
     got = lib.bialign_abi_version()
     if got != ABI_VERSION:
         raise ImportError(f"libbialign_hip.so ABI {got} != expected {ABI_VERSION}; rebuild")
+    exp = lib.bialign_build_experiment()
+    if exp and os.environ.get("BIALIGN_ALLOW_EXPERIMENT_BUILD") != str(exp):
+        # BIALIGN_LIB_OVERRIDE may point at a timing build (tools/exp_build.sh) whose results are wrong by construction:
+        # never silently.  The timing tools say which experiment they expect.
+        raise ImportError(f"{LIB_PATH} is a kernel timing experiment (BIALIGN_EXP={exp}), not a product build; "
+                          f"set BIALIGN_ALLOW_EXPERIMENT_BUILD={exp} to time it")
     return lib
 
 

@@ -7,28 +7,78 @@ over the ranks of a one-process-per-GPU job.
 """
 import bisect
 
+import numpy as np
+
 from .scoring import ScoreModel
 
 
+class FlatBatch:
+    """A batch's molecules as the C ABI wants them (include/bialign.h, bialign_pairs): one uint8 code array per
+    side and kind, pair p's molecule A at ``seq_a[off_a[p] : off_a[p] + len_a[p]]``."""
+    __slots__ = ("len_a", "len_b", "off_a", "off_b", "seq_a", "cls_a", "seq_b", "cls_b")
+
+    def molecules(self, side):
+        """[(sequence codes, class codes)] per pair -- views, nothing is copied."""
+        ln, off = (self.len_a, self.off_a) if side == "a" else (self.len_b, self.off_b)
+        seq, cls = (self.seq_a, self.cls_a) if side == "a" else (self.seq_b, self.cls_b)
+        return [(seq[o:o + n], cls[o:o + n]) for o, n in zip(off.tolist(), ln.tolist())]
+
+
+def _offsets(lens):
+    off = np.zeros(len(lens), dtype=np.int64)
+    np.cumsum(lens[:-1], out=off[1:])
+    return off
+
+
+def encode_flat(pairs, params):
+    """pairs: iterable of (seqA, seqB, strA, strB) -> (ScoreModel, FlatBatch).  The whole batch is encoded in one
+    shot: all molecules of a kind joined into one ``bytes``, one table gather, offsets by cumsum -- no per-molecule
+    numpy call (1024 pairs x len 1024: 45 ms -> 4 ms of host time in front of a 50 ms sweep)."""
+    pairs = pairs if isinstance(pairs, list) else list(pairs)
+    sa, sb, ta, tb = zip(*pairs) if pairs else ((), (), (), ())
+    fb = FlatBatch()
+    fb.len_a = np.fromiter(map(len, sa), dtype=np.int32, count=len(pairs))
+    fb.len_b = np.fromiter(map(len, sb), dtype=np.int32, count=len(pairs))
+    if not (np.array_equal(fb.len_a, np.fromiter(map(len, ta), dtype=np.int32, count=len(pairs))) and
+            np.array_equal(fb.len_b, np.fromiter(map(len, tb), dtype=np.int32, count=len(pairs)))):
+        raise ValueError("Provided structure and sequence must have the same length.")
+    fb.off_a, fb.off_b = _offsets(fb.len_a), _offsets(fb.len_b)
+    na = int(fb.len_a.sum())
+    raw_seq = raw_str = None
+    try:  # latin-1: one byte per letter, so byte offsets are letter offsets
+        raw_seq = ("".join(sa) + "".join(sb)).encode("latin-1")
+        raw_str = ("".join(ta) + "".join(tb)).encode("latin-1")
+    except UnicodeEncodeError:
+        pass
+    if raw_seq is None:
+        model = ScoreModel(params, sequences=sa + sb, structures=ta + tb)
+        seq = cls = None
+    else:
+        model = ScoreModel(params, raw_sequences=raw_seq, raw_structures=raw_str)
+        seq = model.encode_raw(raw_seq, model.seq_index)
+        cls = None if model.is_rna else model.encode_raw(raw_str, model.cls_index)
+    cat = lambda parts: np.concatenate(parts) if parts else np.zeros(0, dtype=np.uint8)
+    if seq is None:  # letters beyond latin-1 or an alphabet without a byte table: molecule by molecule
+        seq = cat([model.encode_sequence(x) for x in sa + sb])
+    if cls is None:  # RNA: classes come from the bracket structure (a stack per molecule); or the slow alphabet path
+        cls = cat([model.encode_structure(x) for x in ta + tb])
+    fb.seq_a, fb.seq_b = seq[:na], seq[na:]   # (contiguous slices of the two joined arrays)
+    fb.cls_a, fb.cls_b = cls[:na], cls[na:]
+    return model, fb
+
+
 def encode_pairs(pairs, params):
-    """pairs: iterable of (seqA, seqB, strA, strB) -> (model, mols_a, mols_b)."""
-    pairs = list(pairs)
-    for sa, sb, ta, tb in pairs:
-        if len(sa) != len(ta) or len(sb) != len(tb):
-            raise ValueError("Provided structure and sequence must have the same length.")
-    model = ScoreModel(params,
-                       sequences=[p[0] for p in pairs] + [p[1] for p in pairs],
-                       structures=[p[2] for p in pairs] + [p[3] for p in pairs])
-    mols_a = [(model.encode_sequence(sa), model.encode_structure(ta)) for sa, _, ta, _ in pairs]
-    mols_b = [(model.encode_sequence(sb), model.encode_structure(tb)) for _, sb, _, tb in pairs]
-    return model, mols_a, mols_b
+    """pairs: iterable of (seqA, seqB, strA, strB) -> (model, mols_a, mols_b), the molecules as
+    (sequence codes, class codes) per pair (views into the flat arrays of ``encode_flat``)."""
+    model, fb = encode_flat(pairs, params)
+    return model, fb.molecules("a"), fb.molecules("b")
 
 
 def make_batch(pairs, params, engine=None, hbm_budget_bytes=0, recurrence=0, mu2_dense=None,
                score_only=False, lean_trace=False):
     from .engine import Batch, default_engine  # loads the HIP library (no CPU fallback)
-    model, mols_a, mols_b = encode_pairs(pairs, params)
-    return Batch(engine or default_engine(), mols_a, mols_b, model.s1, model.s2,
+    model, fb = encode_flat(pairs, params)
+    return Batch(engine or default_engine(), fb, None, model.s1, model.s2,
                  params["gap_opening_cost"], params["gap_cost"], params["shift_cost"],
                  params["max_shift"], hbm_budget_bytes=hbm_budget_bytes, recurrence=recurrence,
                  mu2_dense=mu2_dense, score_only=score_only, lean_trace=lean_trace)

@@ -358,6 +358,8 @@ extern "C" {
 
 int bialign_abi_version(void) { return BIALIGN_ABI_VERSION; }
 
+int bialign_build_experiment(void) { return BIALIGN_EXP; }
+
 const char* bialign_last_error(void) { return g_err.c_str(); }
 
 int bialign_device_count(void) {
@@ -878,7 +880,7 @@ int bialign_batch_dump_layers(bialign_batch* b, int32_t pair, int32_t* out) {
   HIP_TRY(hipSetDevice(b->eng->device));
   hipStream_t st = b->eng->stream;
   // one-pair launch out of the regular launch order (team shape and layer offset are the pair's own)
-  const int pos = (int)(std::find(b->order.begin(), b->order.end(), pair) - b->order.begin());
+  int pos = (int)(std::find(b->order.begin(), b->order.end(), pair) - b->order.begin());
   DeviceBatch v = b->view();
   HIP_TRY(hipMemsetAsync(b->d_err.p, 0, sizeof(int32_t), st));
   b->used_xcu = b->used_pack = false;
@@ -893,7 +895,10 @@ int bialign_batch_dump_layers(bialign_batch* b, int32_t pair, int32_t* out) {
       if (err & 2) {
         b->pack_failed = true;
         if (int rc2 = replan_full(b)) return rc2;
-        v = b->view();  // (the layer buffer may have been replaced)
+        // the re-plan sorts every chunk's launch order anew, moves every pair's layer_off and may have replaced
+        // the layer buffer: the pair's launch position and the device view are the new ones from here on
+        v = b->view();
+        pos = (int)(std::find(b->order.begin(), b->order.end(), pair) - b->order.begin());
       }
       ++b->recovered;
       HIP_TRY(hipMemsetAsync(b->d_err.p, 0, sizeof(int32_t), st));

@@ -69,7 +69,8 @@ def default_engine(device=0):
 class Batch:
     """A set of independent pairs sharing one parameter set, resident in HBM.
 
-    ``mols_a`` / ``mols_b``: lists of ``(seq_codes uint8[n], class_codes uint8[n])``.
+    ``mols_a`` / ``mols_b``: lists of ``(seq_codes uint8[n], class_codes uint8[n])`` -- or ``mols_a`` a
+    ``batch.FlatBatch`` (the whole batch's code arrays, as ``batch.encode_flat`` makes them) and ``mols_b`` None.
     ``s1`` / ``s2``: int32 score tables (k1 x k1, k2 x k2).
     ``mu2_dense``: optional list of int32 arrays, pair p's of shape (n_p, m_p) with entry
     [k-1, l-1] = mu2(k, l); replaces the class codes / ``s2`` (DENSE form of include/bialign.h).
@@ -82,21 +83,28 @@ class Batch:
     def __init__(self, engine, mols_a, mols_b, s1, s2, gap_opening_cost, gap_cost, shift_cost,
                  max_shift, hbm_budget_bytes=0, recurrence=0, mu2_dense=None, score_only=False,
                  lean_trace=False):
-        if len(mols_a) != len(mols_b) or not mols_a:
-            raise ValueError("need the same, non-zero number of A and B molecules")
+        if mols_b is None and hasattr(mols_a, "seq_a"):  # a batch.FlatBatch: the arrays are the ABI's already
+            fb = mols_a
+            if not len(fb.len_a):
+                raise ValueError("need the same, non-zero number of A and B molecules")
+            self.len_a, self.len_b, off_a, off_b = fb.len_a, fb.len_b, fb.off_a, fb.off_b
+            seq_a, cls_a, seq_b, cls_b = fb.seq_a, fb.cls_a, fb.seq_b, fb.cls_b
+        else:
+            if len(mols_a) != len(mols_b) or not mols_a:
+                raise ValueError("need the same, non-zero number of A and B molecules")
+            self.len_a = np.array([len(x[0]) for x in mols_a], dtype=np.int32)
+            self.len_b = np.array([len(x[0]) for x in mols_b], dtype=np.int32)
+            off_a = np.zeros(len(mols_a), dtype=np.int64)
+            off_b = np.zeros(len(mols_a), dtype=np.int64)
+            off_a[1:] = np.cumsum(self.len_a[:-1])
+            off_b[1:] = np.cumsum(self.len_b[:-1])
+            seq_a = np.ascontiguousarray(np.concatenate([np.asarray(x[0], dtype=np.uint8) for x in mols_a]))
+            cls_a = np.ascontiguousarray(np.concatenate([np.asarray(x[1], dtype=np.uint8) for x in mols_a]))
+            seq_b = np.ascontiguousarray(np.concatenate([np.asarray(x[0], dtype=np.uint8) for x in mols_b]))
+            cls_b = np.ascontiguousarray(np.concatenate([np.asarray(x[1], dtype=np.uint8) for x in mols_b]))
         self.engine = engine
-        self.npairs = len(mols_a)
-        self.len_a = np.array([len(x[0]) for x in mols_a], dtype=np.int32)
-        self.len_b = np.array([len(x[0]) for x in mols_b], dtype=np.int32)
+        self.npairs = len(self.len_a)
         self.max_shift = int(max_shift)
-        off_a = np.zeros(self.npairs, dtype=np.int64)
-        off_b = np.zeros(self.npairs, dtype=np.int64)
-        off_a[1:] = np.cumsum(self.len_a[:-1])
-        off_b[1:] = np.cumsum(self.len_b[:-1])
-        seq_a = np.ascontiguousarray(np.concatenate([np.asarray(x[0], dtype=np.uint8) for x in mols_a]))
-        cls_a = np.ascontiguousarray(np.concatenate([np.asarray(x[1], dtype=np.uint8) for x in mols_a]))
-        seq_b = np.ascontiguousarray(np.concatenate([np.asarray(x[0], dtype=np.uint8) for x in mols_b]))
-        cls_b = np.ascontiguousarray(np.concatenate([np.asarray(x[1], dtype=np.uint8) for x in mols_b]))
         if len(seq_a) != len(cls_a) or len(seq_b) != len(cls_b):
             raise ValueError("sequence and structure codes must have equal length")
         s1 = np.ascontiguousarray(s1, dtype=np.int32)
@@ -131,10 +139,14 @@ class Batch:
         check(lib.bialign_batch_create(engine._h, ctypes.byref(prm), ctypes.byref(sc), ctypes.byref(pr),
                                        int(hbm_budget_bytes), ctypes.byref(self._h)))
         engine._batches.add(self)
+        self.info = self.current_info()
+        self.affine = bool(self.info["affine"])
+
+    def current_info(self):
+        """bialign_batch_get_info now (``info`` is the answer at creation; a fallback to full records may re-chunk)."""
         info = _lib.BatchInfo()
         check(lib.bialign_batch_get_info(self._h, ctypes.byref(info)))
-        self.info = {k: getattr(info, k) for k, _ in info._fields_}
-        self.affine = bool(info.affine)
+        return {k: getattr(info, k) for k, _ in info._fields_}
 
     def close(self):
         if getattr(self, "_h", None):

@@ -75,10 +75,23 @@ def rna_classes(structure):
     return cls
 
 
+def _alphabet(texts=(), raw=None):
+    """Sorted distinct letters: of the molecules' joined latin-1 bytes when the caller has them (C-speed passes:
+    the letters of the first 4 KiB are deleted from the rest until nothing is left), else of the strings."""
+    if raw is not None:
+        letters, rest = set(), raw
+        while rest:
+            new = set(rest[:4096])
+            letters |= new
+            rest = rest.translate(None, bytes(new))
+        return [chr(c) for c in sorted(letters)]
+    return sorted(set("".join(texts)))
+
+
 class ScoreModel:
     """Alphabets + tables for one parameter set; encodes molecules to codes."""
 
-    def __init__(self, params, sequences=(), structures=()):
+    def __init__(self, params, sequences=(), structures=(), raw_sequences=None, raw_structures=None):
         self.is_rna = params["type"] == "RNA"
         sw = int(params["structure_weight"])
         if params.get("simmatrix"):
@@ -86,7 +99,7 @@ class ScoreModel:
             self.seq_keys = list(keys)
             self.s1 = (100 * mat).astype(np.int32)
         else:
-            letters = sorted(set("".join(sequences)))
+            letters = _alphabet(sequences, raw_sequences)
             if not letters:
                 letters = ["N"]
             self.seq_keys = letters
@@ -100,7 +113,7 @@ class ScoreModel:
             self.cls_keys = ["unp", "down", "up"]
             k2 = 3
         else:
-            letters = sorted(set("".join(structures))) or ["C"]
+            letters = _alphabet(structures, raw_structures) or ["C"]
             self.cls_keys = letters
             k2 = len(letters)
             if k2 > 256:
@@ -109,18 +122,35 @@ class ScoreModel:
         self.s2 = np.zeros((k2, k2), dtype=np.int32)
         np.fill_diagonal(self.s2, sw)  # pyx:425-428 / 416-423 with 0/1 features
 
-    def _encode(self, text, index):
-        """Letters -> uint8 codes through a 256-entry table (one numpy gather per molecule); the
-        first letter outside the alphabet raises KeyError like the reference's dict look-up."""
+    def _lut(self, index):
+        """256-entry letter -> code table (255 = not in the alphabet), or False for an exotic alphabet."""
         luts = self.__dict__.setdefault("_luts", {})
         lut = luts.get(id(index))
         if lut is None:
-            lut = False  # exotic alphabet: per-letter path below
+            lut = False  # exotic alphabet: per-letter path
             if len(index) < 255 and all(len(c) == 1 and ord(c) < 256 for c in index):
                 lut = np.full(256, 255, dtype=np.uint8)
                 for c, x in index.items():
                     lut[ord(c)] = x
             luts[id(index)] = lut
+        return lut
+
+    def encode_raw(self, raw, index):
+        """The whole batch at once: the molecules' joined latin-1 ``bytes`` -> uint8 codes by ONE ``bytes.translate``
+        (None if this alphabet has no byte table).  A letter outside the alphabet raises KeyError like the reference."""
+        lut = self._lut(index)
+        if lut is False:
+            return None
+        codes = raw.translate(lut.tobytes())
+        bad = codes.find(b"\xff")
+        if bad >= 0:
+            raise KeyError(chr(raw[bad]))
+        return np.frombuffer(codes, dtype=np.uint8)
+
+    def _encode(self, text, index):
+        """Letters -> uint8 codes through a 256-entry table (one numpy gather per molecule); the
+        first letter outside the alphabet raises KeyError like the reference's dict look-up."""
+        lut = self._lut(index)
         if lut is not False:
             try:
                 raw = np.frombuffer(text.encode("latin-1"), dtype=np.uint8)

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define BIALIGN_ABI_VERSION 8
+#define BIALIGN_ABI_VERSION 9
 
 #define BIALIGN_OK 0
 #define BIALIGN_E_INVALID (-1)     /* bad argument (message says which) */
@@ -143,6 +143,11 @@ typedef struct bialign_timing {
 } bialign_timing;
 
 int bialign_abi_version(void);
+/* 0 for a product build.  Non-zero: the library was compiled as a kernel TIMING experiment (-DBIALIGN_EXP=n,
+   tools/exp_build.sh: sweeps without stores, without hand-off waits, ...) whose results are wrong by
+   construction; a binding must refuse such a library (bialign_amd/_lib.py does).  Replaces nothing in the
+   reference. */
+int bialign_build_experiment(void);
 /* Number of visible HIP devices (<0 on error). */
 int bialign_device_count(void);
 const char* bialign_last_error(void);

@@ -50,3 +50,25 @@ def test_product_never_imports_oracle():
                 with open(os.path.join(root, f)) as fh:
                     src = fh.read()
                 assert "oracle" not in src.lower() or f == "verify.py", os.path.join(root, f)
+
+
+def test_timing_experiment_builds_are_refused(tmp_path):
+    """BIALIGN_LIB_OVERRIDE may name another build of the engine; one compiled as a kernel timing experiment
+    (-DBIALIGN_EXP=n: wrong results by construction) must not load silently.  A stub with the header's symbols
+    stands in for such a build (a real one takes a minute of hipcc)."""
+    import subprocess
+    import sys
+    from bialign_amd import _lib
+    body = "".join(f"long {n}(void) {{ return {_lib.ABI_VERSION if n == 'bialign_abi_version' else (3 if n == 'bialign_build_experiment' else 0)}; }}\n"
+                   for n, _, _ in _lib.SYMBOLS)
+    src, so = tmp_path / "stub.c", tmp_path / "libstub.so"
+    src.write_text(body)
+    subprocess.run(["gcc", "-shared", "-fPIC", "-o", str(so), str(src)], check=True)
+    env = dict(os.environ, BIALIGN_LIB_OVERRIDE=str(so), PYTHONPATH=REPO)
+    env.pop("BIALIGN_ALLOW_EXPERIMENT_BUILD", None)
+    r = subprocess.run([sys.executable, "-c", "import bialign_amd._lib"], env=env, capture_output=True, text=True)
+    assert r.returncode != 0 and "timing experiment (BIALIGN_EXP=3)" in r.stderr
+    r = subprocess.run([sys.executable, "-c", "import bialign_amd._lib"], env=dict(env, BIALIGN_ALLOW_EXPERIMENT_BUILD="3"),
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert _lib.lib.bialign_build_experiment() == 0   # the shipped library is a product build

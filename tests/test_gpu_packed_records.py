@@ -208,6 +208,48 @@ def test_fallback_replans_a_chunked_batch(monkeypatch):
         assert bool(ok[k]) == ref["complete"]
 
 
+def test_dump_layers_first_fill_overflows_and_replans(monkeypatch):
+    """The layer dump is where a batch's FIRST fill happens (no run() before it), the offsets overflow, and the
+    re-plan by full-record sizes under a tight budget re-chunks and re-orders the batch: the dump must refill and
+    read the pair at its NEW launch position and layer offset -- every cell of two pairs against the oracle --
+    and a run() afterwards must equal the oracle too."""
+    from oracle import oracle
+    from bialign_amd.batch import make_batch
+    from bialign_amd.engine import trace_codes_to_columns
+    monkeypatch.setenv("BIALIGN_PACK", "1")
+    params = dict(synth.PROTEIN_PARAMS, simmatrix=None, sequence_match_similarity=5000, sequence_mismatch_similarity=-5000,
+                  structure_weight=100, gap_opening_cost=-5000, gap_cost=-5000, shift_cost=-5000)
+    lens = [(125, 150), (190, 140), (140, 185), (170, 170)]   # launch order (longest sweep first) differs from pair order
+    pairs = [synth.protein_pair(4900 + t, n, m) for t, (n, m) in enumerate(lens)]
+    probe = make_batch(pairs, params)
+    one_chunk = probe.info["hbm_layer_bytes"]
+    probe.close()
+    b = make_batch(pairs, params, hbm_budget_bytes=int(one_chunk * 0.62))
+    chunks_before = b.info["nchunks"]
+    assert chunks_before >= 2
+    refs = [oracle.solve(*pair, params) for pair in pairs]
+    for k in (2, 0):     # before any run(): the first dump overflows, re-plans and repeats; the second finds the batch on full records
+        n, m = lens[k]
+        got = b.dump_layers(k)
+        for g, e in zip(oracle.band_values(got, n, m, 1), oracle.band_values(refs[k]["layers"], n, m, 1)):
+            np.testing.assert_array_equal(g, e)
+    assert b.current_info()["nchunks"] >= chunks_before     # full records need at least as many chunks
+    b.run()
+    t = b.timing()
+    assert not t["packed_records"] and t["recovered_runs"] >= 1
+    scores = b.scores()
+    traces, ok = b.traces()
+    for k in (3, 1):     # and after a run
+        n, m = lens[k]
+        for g, e in zip(oracle.band_values(b.dump_layers(k), n, m, 1), oracle.band_values(refs[k]["layers"], n, m, 1)):
+            np.testing.assert_array_equal(g, e)
+    b.close()
+    for k, ref in enumerate(refs):
+        assert int(scores[k]) == ref["score"]
+        assert trace_codes_to_columns(traces[k]) == oracle.trace_to_lists(ref["trace"])
+        assert bool(ok[k]) == ref["complete"]
+
+
 def test_s3_policy_by_batch_size():
     from bialign_amd.batch import make_batch
     params = dict(synth.PROTEIN_PARAMS, max_shift=3)
