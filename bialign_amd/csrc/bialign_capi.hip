@@ -61,6 +61,37 @@ TeamShape team_shape(const bialign_batch* b, int first, int count, int xcu_resid
 
   const char* e = getenv("BIALIGN_TEAM");  // experiments / tests: "N" in-workgroup, "xN" cross-CU, "hN" N eight-wave workgroups
   if (e && !*e) e = nullptr;
+  // The three-waves-per-SIMD sweep (fill_affine_slim_kernel: 168 registers, no exchange array): workgroups of 1, 2, 3, 6
+  // or 12 waves, always twelve waves per CU.  Taken whenever it keeps at least as many waves running as the two-wave
+  // kernels' best shape -- a SIMD runs three such waves at the per-wave speed of two (tools/valu_rate.hip).
+  if (slim_available(b) && !(e && (e[0] == 'x' || e[0] == 'h'))) {
+    // a workgroup = 12 waves = (12 / t) pairs x teams of t, one per CU: every SIMD holds exactly three waves
+    auto conc_slim = [&](int t) { return std::min<int64_t>((int64_t)count * t, (int64_t)b->eng->num_cu * 12); };
+    auto fits = [&](int t) { return t <= fit_exact && b->lds_slim(t) <= 160 * 1024; };
+    static const int sizes[] = {1, 2, 3, 6, 12};
+    int pick = 0;
+    if (e) {  // forced in-workgroup team: the slim kernel if it comes in that size
+      const int want = atoi(e);
+      for (int t : sizes)
+        if (t == want && fits(t)) pick = t;
+    } else {
+      int64_t best_s = 0;
+      for (int t : sizes)
+        if (fits(t)) best_s = std::max(best_s, conc_slim(t));
+      for (int t : sizes)
+        if (!pick && fits(t) && conc_slim(t) * 100 >= best_s * 95) pick = t;
+    }
+    if (pick) {
+      // (a handful of long pairs still go to cross-CU teams of the two-wave kernel below when that spreads them wider)
+      const int64_t run_s = conc_slim(pick);
+      const int g = std::min(gw, std::max(1, 2048 / count));
+      if (e || !(g >= 2 && (int64_t)count * g * 10 >= run_s * 14)) {
+        ts.tw = pick;
+        ts.slim = true;
+        return ts;
+      }
+    }
+  }
   if (e && e[0] == 'x') {
     ts.gw = std::max(1, std::min(atoi(e + 1), gw));
     return ts;
@@ -191,6 +222,20 @@ size_t lds_need(int S, int NL, int team, int k1, int k2, int n, int m, bool dens
   const size_t shared_dw = 16 + (size_t)k1 * k1 + (size_t)k2 * k2;  // progress words + score tables
   const size_t mu2_ring_dw = dense ? 2 * (size_t)blk * 64 : 0;  // Mu2Feed<S>::RING_DW
   return (team * (ring_dw + nv * NCOL + mu2_ring_dw) + shared_dw) * 4 + 2 * npad + 2 * mpad;
+}
+
+// fill_affine_slim_kernel (bialign_fill_slim.hpp), a workgroup of twelve waves: twelve ghost rings, a block of sentinels,
+// progress words, score tables (lds_need_slim_base); per pair of the workgroup both molecules' codes (lds_need_slim_codes)
+size_t lds_need_slim_base(int S, int k1, int k2) {
+  const int W = 2 * S + 1;
+  const int nd = 9 * W, np = nd / 4 + (nd % 4 ? 1 : 0), blk = ghost_blk(S);
+  const size_t ring_dw = 2 * (((size_t)blk * W * np + 63) / 64 * 64) * 4;  // GhostFeed<S,9>::RING_DW
+  return (12 * ring_dw + 4 * np + 16 + (size_t)k1 * k1 + (size_t)k2 * k2) * 4;
+}
+size_t lds_need_slim_codes(int S, int n, int m) {
+  const int PADB = S + 1;
+  const size_t npad = (n + 3) & ~3, mpad = (m + 2 * PADB + 3) & ~3;
+  return 2 * npad + 2 * mpad;
 }
 
 int launch_fill(bialign_batch* b, const DeviceBatch& v, int first, int count) {
@@ -490,12 +535,14 @@ int bialign_batch_create(bialign_engine* eng, const bialign_params* prm, const b
       b->lds_bytes = std::max(b->lds_bytes, lds_need(S, b->NL, 1, sc->k1, sc->k2, n, m, b->dense));
       b->lds_base = std::max(b->lds_base, lds_need(S, b->NL, 0, sc->k1, sc->k2, n, m, b->dense));
       b->lds_diet8 = std::max(b->lds_diet8, lds_need(S, b->NL, 8, sc->k1, sc->k2, n, m, false, true));
+      b->lds_slim_codes = std::max(b->lds_slim_codes, lds_need_slim_codes(S, n, m));
     }
     b->lds_trace = std::max<size_t>(b->lds_trace, ((size_t)sc->k1 * sc->k1 + (size_t)sc->k2 * sc->k2) * 4 +
                                                       2 * (size_t)((n + 3) & ~3) + 2 * (size_t)((m + 3) & ~3));
   }
   if (!b->wide)
     b->lds_per_wave = lds_need(S, b->NL, 1, sc->k1, sc->k2, 1, 1, b->dense) - lds_need(S, b->NL, 0, sc->k1, sc->k2, 1, 1, b->dense);
+  if (!b->wide) b->lds_slim_base = lds_need_slim_base(S, sc->k1, sc->k2);
   if (std::max(b->lds_bytes, b->lds_trace) > 160 * 1024)
     return fail(BIALIGN_E_UNSUPPORTED, "molecules too long for the LDS staging (%zu bytes needed, 160 KiB per workgroup)",
                 std::max(b->lds_bytes, b->lds_trace));

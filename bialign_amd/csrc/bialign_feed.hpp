@@ -66,7 +66,7 @@ struct GhostFeed {
     }
   }
   // The same for a sweep with packed records (Pack<S>): the source of a piece is the packed record of an
-  // interior step (NCH pieces per lane; the surplus lanes of a round re-read piece 0) or the full record of
+  // interior step (NPC pieces per lane; the surplus lanes of a round re-read piece 0) or the full record of
   // any other step in the pair's second region (starting at dword bnd_off).  Not used by re-sweeps (Qbase = 0).
   __device__ static __forceinline__ void issue_packed(const int32_t* lay, int64_t bnd_off, int m, int h0, int blk_q,
                                                       int blk_rem, int P, int T, int w, int rec_last, int lane,
@@ -86,8 +86,8 @@ struct GhostFeed {
       const bool valid = rec >= 0 && rec <= rec_last;
       const int sl = (R - 2) * W + aa;  // storage slot of the bottom real row
       const int32_t* p;
-      if (valid && PK::interior(qs, cs, m))
-        p = lay + rec * PK::RECDW + (c < PK::NCH ? c : 0) * R_::CH + sl * 4;
+      if (valid && PK::interior(qs, cs, m))  // pieces 0 .. NCH-1: the 16-byte chunks; piece NCH: the tail (TAILDW dwords, read 16 bytes wide)
+        p = lay + rec * PK::RECDW + (c < PK::NCH ? c * R_::CH + sl * 4 : (c == PK::NCH && PK::TAILDW ? PK::NCH * R_::CH + sl * PK::TAILDW : sl * 4));
       else
         p = lay + bnd_off + (valid ? PK::bidx(qs, cs, P, m) : 0) * R_::RECDW +
             (c < R_::NCH4 ? c * R_::CH + sl * 4 : R_::NCH4 * R_::CH + sl * R_::TAIL);

@@ -74,7 +74,7 @@ __device__ __forceinline__ void store_chunk(int32_t* p, v4i v, bool wt) {
 //   PACK: interior steps store packed records, the others full records in the pair's second region (Pack<S>).
 template <int S, bool BETA_NONPOS, int TW, bool XCU, bool DENSE = false, bool LEAN = false, bool RESW = false,
           bool PACK = false>
-__global__ void __launch_bounds__(64 * TW) fill_affine_kernel(const DeviceBatch A) {
+__global__ void __launch_bounds__(64 * TW) BIALIGN_WPE_ATTR fill_affine_kernel(const DeviceBatch A) {
   static_assert(!PACK || (!LEAN && !RESW && S >= 1), "packed records: full-storage sweeps with a band");
   using PK_ = Pack<S>;
   // Ghost rows of packed records: unpacked once per block by BLK*W lanes (s=1: 24 lanes every 8 steps, -4 % fill
@@ -279,11 +279,12 @@ __global__ void __launch_bounds__(64 * TW) fill_affine_kernel(const DeviceBatch 
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   int vm_younger = 0;  // store instructions issued since the last block's DMAs (wave-uniform)
 
-  // Exchange inputs of rows i-1 (what lanes L-W, L-W+1 published for each band column).  BIALIGN_OPT & 8: they are
-  // loop-carried -- row r is fetched from the exchange array at the END of a step, as soon as its last consumer of
-  // that step is through, for the step after it: the LDS round trip (publish -> read) overlaps the rest of the step
-  // instead of standing at the head of the next one.  Likewise (BIALIGN_OPT & 16) the score inputs of the next
-  // column: the two dependent LDS reads (code byte, then table entry) leave the head of the step.
+  // Exchange inputs of rows i-1 (what lanes L-W, L-W+1 published for each band column).  They are loop-carried:
+  // row r is fetched from the exchange array at the END of a step, as soon as its last consumer of that step is
+  // through, for the step after it -- the LDS round trip (publish -> read) overlaps the rest of the step instead
+  // of standing at the head of the next one.  Likewise the score inputs of the next column: the two dependent LDS
+  // reads (code byte, then table entry) leave the head of the step (-1 % fill time at len 1024; the sweep is bound by
+  // VALU issue, profiles/r03a_headline_baseline).
   int inA[W][4], inB[W][8];
   auto read_lds = [&](int r) __attribute__((always_inline)) {
 #pragma unroll
@@ -291,12 +292,14 @@ __global__ void __launch_bounds__(64 * TW) fill_affine_kernel(const DeviceBatch 
 #pragma unroll
     for (int x = 0; x < 8; ++x) inB[r][x] = xch[(r * XR + 4 + x) * NCOL + colLW1];
   };
-  // A delay-line stage.  With the loop-carried exchange inputs the copy is opaque to the compiler: coalescing it
-  // would keep the old value alive in the register the next fetch wants, and the allocator then copies the freshly
-  // fetched values at the back-edge instead -- behind an lgkmcnt wait, which is the stall the early fetch was to hide.
-  auto dmov = [](int& dst, int src) __attribute__((always_inline)) {
-    if (BIALIGN_OPT & 8) asm("v_mov_b32 %0, %1" : "=v"(dst) : "v"(src));
-    else dst = src;
+  // A delay-line stage.  The copy is opaque to the compiler: coalescing it would keep the old value alive in the
+  // register the next fetch wants, and the allocator then copies the freshly fetched values at the back-edge instead
+  // -- behind an lgkmcnt wait, which is the stall the early fetch was to hide.  (Moving two stages as one register
+  // pair buys nothing: on gfx950 v_mov_b64 costs a SIMD 4.3 cycles, two v_mov_b32 4.8 -- tools/valu_rate.hip.)
+  auto dmov = [](int& dst, int src) __attribute__((always_inline)) { asm("v_mov_b32 %0, %1" : "=v"(dst) : "v"(src)); };
+  auto dmov2 = [&](int& d0, int& d1, int s0, int s1) __attribute__((always_inline)) {
+    dmov(d0, s0);
+    dmov(d1, s1);
   };
   int mu1n = 0, mu2n[W];
   auto lookup_mu = [&]() __attribute__((always_inline)) {  // score inputs of the column this lane works on next (LOOKUP form)
@@ -305,10 +308,8 @@ __global__ void __launch_bounds__(64 * TW) fill_affine_kernel(const DeviceBatch 
 #pragma unroll
     for (int bb = 0; bb < W; ++bb) mu2n[bb] = DENSE ? 0 : s2[s2row + cb[jc + bb]];  // l-1+PADB = jc+bb
   };
-  if (BIALIGN_OPT & 8) {
 #pragma unroll
-    for (int r = 0; r < W; ++r) read_lds(r);
-  }
+  for (int r = 0; r < W; ++r) read_lds(r);
   // ... and, one step further ahead, the two codes an interior step's end looks up (column jj + 1 of the same row)
   int sbn = 0, cbn = 0;
   auto fetch_codes = [&]() __attribute__((always_inline)) {
@@ -316,10 +317,8 @@ __global__ void __launch_bounds__(64 * TW) fill_affine_kernel(const DeviceBatch 
     sbn = sb[jc1 - 1 + PADB];
     cbn = DENSE ? 0 : cb[jc1 + W - 1];
   };
-  if (BIALIGN_OPT & 16) {
-    lookup_mu();
-    fetch_codes();
-  }
+  lookup_mu();
+  fetch_codes();
 
   // One step of the sweep.  INTERIOR steps (every lane's lattice points have all
   // four coordinates >= 1 and lie inside the molecule columns; ~90 % of the
@@ -350,17 +349,17 @@ __global__ void __launch_bounds__(64 * TW) fill_affine_kernel(const DeviceBatch 
           const int ts = ph + 2 * (R - 1), over = ts >= P ? 1 : 0;
           if (PK_::interior(qst - 1 + over, ts - over * P, m)) {
             v4i* pc = ring + ghalf * GF::SLOTS + (t * W + ai) * GF::NP;
-            int raw[4 * PK_::NCH], dec[4 * GF::NP];
+            int raw[4 * PK_::NPC], dec[4 * GF::NP];
 #pragma unroll
-            for (int c = 0; c < PK_::NCH; ++c) {
+            for (int c = 0; c < PK_::NPC; ++c) {
               const v4i v = pc[c];
               raw[4 * c] = v.x; raw[4 * c + 1] = v.y; raw[4 * c + 2] = v.z; raw[4 * c + 3] = v.w;
             }
 #pragma unroll
             for (int d = 0; d < 4 * GF::NP; ++d) {
-              const int h = 2 + d;
-              const unsigned word = (unsigned)raw[d < ND ? h >> 1 : 0];
-              const unsigned e = (h & 1) ? word >> 16 : word & 0xffffu;
+              const int h = PK_::hw(d < ND ? d : 0);
+              const unsigned word = (unsigned)raw[d < ND && d != PK_::ANCHOR ? h >> 1 : 0];
+              const unsigned e = d == PK_::ANCHOR ? 0x8000u : ((h & 1) ? word >> 16 : word & 0xffffu);
               const int v = raw[0] + (int)e;
               dec[d] = d >= ND ? 0 : (pack_corner(W, d % 9, d / 9) ? (e == 0xffffu ? NEG : v) : v);
             }
@@ -394,13 +393,13 @@ __global__ void __launch_bounds__(64 * TW) fill_affine_kernel(const DeviceBatch 
       ghost_packed = PK_::interior(q0 * T + w - 1 + over, ts - over * P, m);
     }
     if (PACK && !PK_COOP && ghost_packed) {
-      int raw[4 * PK_::NCH];
-      GF::template fetch_pieces<PK_::NCH>(raw, ring + ghalf * GF::SLOTS, gt, aa);
+      int raw[4 * PK_::NPC];
+      GF::template fetch_pieces<PK_::NPC>(raw, ring + ghalf * GF::SLOTS, gt, aa);
 #pragma unroll
       for (int d = 0; d < ND; ++d) {
-        const int h = 2 + d;
-        const unsigned word = (unsigned)raw[h >> 1];
-        const unsigned e = (h & 1) ? word >> 16 : word & 0xffffu;
+        const int h = PK_::hw(d);
+        const unsigned word = (unsigned)raw[d != PK_::ANCHOR ? h >> 1 : 0];
+        const unsigned e = d == PK_::ANCHOR ? 0x8000u : ((h & 1) ? word >> 16 : word & 0xffffu);
         const int v = raw[0] + (int)e;
         ghostM[d] = pack_corner(W, d % 9, d / 9) ? (e == 0xffffu ? NEG : v) : v;
       }
@@ -413,7 +412,6 @@ __global__ void __launch_bounds__(64 * TW) fill_affine_kernel(const DeviceBatch 
     //         (all of them up front for W <= 3): a sliding window keeps registers flat in W.
     int inC[W][8];
     auto read_rows = [&](int r) __attribute__((always_inline)) {
-      if (!(BIALIGN_OPT & 8)) read_lds(r);
       // lane L-1 = (i, a-1) hands its values over in registers: one DPP wave shift fused with a min
       // against the lane's cap (the sentinel where a-1 leaves the band, INT_MAX elsewhere).  One asm
       // block per band column: the compiler's own DPP folding gives up once the consumers are sunk
@@ -459,8 +457,7 @@ __global__ void __launch_bounds__(64 * TW) fill_affine_kernel(const DeviceBatch 
     if (W > 1) read_rows(W > 1 ? 1 : 0);
 
     // ---- 2. score inputs of this column (pyx:260-261; LOOKUP form)
-    const int jc = INTERIOR ? jj : min(max(jj, 0), m + 1);
-    const int mu1 = (BIALIGN_OPT & 16) ? mu1n : s1[s1row + sb[jc - 1 + PADB]];
+    const int mu1 = mu1n;
     int mu2[W];
     if (DENSE) {  // slide the window, take this step's new value from the ring
 #pragma unroll
@@ -468,12 +465,9 @@ __global__ void __launch_bounds__(64 * TW) fill_affine_kernel(const DeviceBatch 
       mu2w[W - 1] = mu2ring[(ghalf * MF::BLK + gt) * 64 + L];
 #pragma unroll
       for (int bb = 0; bb < W; ++bb) mu2[bb] = mu2w[bb];
-    } else if (BIALIGN_OPT & 16) {
-#pragma unroll
-      for (int bb = 0; bb < W; ++bb) mu2[bb] = mu2n[bb];
     } else {
 #pragma unroll
-      for (int bb = 0; bb < W; ++bb) mu2[bb] = s2[s2row + cb[jc + bb]];  // l-1+PADB = jc+bb
+      for (int bb = 0; bb < W; ++bb) mu2[bb] = mu2n[bb];
     }
 
     const bool tile_act = INTERIOR ? true : (act_row && jj >= 0 && jj <= m);
@@ -493,7 +487,7 @@ __global__ void __launch_bounds__(64 * TW) fill_affine_kernel(const DeviceBatch 
                           (INTERIOR || __builtin_amdgcn_ballot_w64(tile_act && !ghost) != 0) &&
                           ((!XCU && TW == 1) || rec <= rec_last);
     const int slot = LEAN ? aa : (pad_lane ? R_::SL + pad_idx : L - W);  // storage slot of this lane
-    if (__builtin_amdgcn_ballot_w64(do_store) != 0) vm_younger += (PACK && INTERIOR) ? PK_::NCH : GF::STORES_PER_STEP;
+    if (__builtin_amdgcn_ballot_w64(do_store) != 0) vm_younger += (PACK && INTERIOR) ? PK_::NPC : GF::STORES_PER_STEP;
     int32_t* dst = BIALIGN_EXP == 2
                        ? A.layers + ((int64_t)(blockIdx.x & 255) << 18) + (int64_t)(g & 31) * RECDW
                        : sto + (int64_t)rec * RECDW;
@@ -555,9 +549,16 @@ __global__ void __launch_bounds__(64 * TW) fill_affine_kernel(const DeviceBatch 
 
           int t = SENT;
           bool any = false;
-          if (ok1) { t = c1 + gin; any = true; }
-          if (ok2) { t = any ? imax(t, c2 + h2in) : c2 + h2in; any = true; }
-          if (ok3) { t = any ? imax(t, c3 + h3in) : c3 + h3in; any = true; }
+          if (BIALIGN_OPT2 && hU < 2 && hV < 2 && ok2 && ok3) {
+            // both gap-gap groups cost gamma + Delta: max(c1 + g, gD + h2, gD + h3) = gD + max(g + (c1 - gD), h2, h3),
+            // exact in integers, one add less (c1 - gD is wave-uniform: gamma - Delta or gamma + Delta)
+            const int inner = ok1 ? imax(imax(gin + (c1 - gD), h2in), h3in) : imax(h2in, h3in);
+            t = gD + inner;
+          } else {
+            if (ok1) { t = c1 + gin; any = true; }
+            if (ok2) { t = any ? imax(t, c2 + h2in) : c2 + h2in; any = true; }
+            if (ok3) { t = any ? imax(t, c3 + h3in) : c3 + h3in; any = true; }
+          }
           Tv[3 * hU + hV] = t;
         }
       }
@@ -566,6 +567,7 @@ __global__ void __launch_bounds__(64 * TW) fill_affine_kernel(const DeviceBatch 
       // finalise: ghost rows take the stored layers; "no valid case" -> -2^30
       // (pyx:299-303); points outside the lattice carry the sentinel.
       int M[9];
+      bool isneg[9] = {};  // "no valid case" per corner state, as the finalisation found it (computing lanes)
       if (INTERIOR && (BIALIGN_OPT & 2)) {
         // ghost lanes keep what the ring delivered; the others compute in place under the
         // execution mask (no per-value select)
@@ -577,7 +579,10 @@ __global__ void __launch_bounds__(64 * TW) fill_affine_kernel(const DeviceBatch 
 #pragma unroll
           for (int q = 0; q < 9; ++q) {
             int tv = Tv[q];
-            if (can_be_empty<W>(q / 3, q % 3, bb)) tv = tv < THRESH ? NEG : tv;
+            if (can_be_empty<W>(q / 3, q % 3, bb)) {
+              isneg[q] = tv < THRESH;
+              tv = isneg[q] ? NEG : tv;
+            }
             M[q] = tv;
           }
         }
@@ -613,14 +618,17 @@ __global__ void __launch_bounds__(64 * TW) fill_affine_kernel(const DeviceBatch 
         }
       }
       if (PACK && INTERIOR) {
-        // Packed record (Pack<S>): dword 0 = base, then the ND offsets as unsigned halfwords.  The OR of
-        // all offsets stored by lanes that hold lattice points is range-checked at the end of the step.
+        // Packed record (Pack<S>): dword 0 = base, then the offsets of all values but the anchor (whose offset is
+        // 0x8000 by construction) as unsigned halfwords.  The OR of all offsets stored by lanes that hold lattice
+        // points is range-checked at the end of the step.
         if (bb == 0) pk_base = M[8] - 0x8000;
 #pragma unroll
         for (int q = 0; q < 9; ++q) {
+          if (bb * 9 + q == PK_::ANCHOR) continue;
           int e = M[q] - pk_base;
           if (pack_corner(W, q, bb)) {  // 0xffff is the -2^30 mark here: a finite value must stay below it
-            const bool ng = M[q] == NEG;
+            // (a finite value that happens to equal -2^30 is not marked: its offset then fails the range check)
+            const bool ng = (BIALIGN_OPT2 != 0 && (BIALIGN_OPT & 2) != 0) ? isneg[q] : M[q] == NEG;
             pk_acc |= ng ? 0 : e + 1;
             e = ng ? 0xffff : e;
           } else {
@@ -630,8 +638,10 @@ __global__ void __launch_bounds__(64 * TW) fill_affine_kernel(const DeviceBatch 
         }
         if (do_store) {
 #pragma unroll
-          for (int c = 0; c < PK_::NCH; ++c) {
-            const int last = 8 * c + 5 < ND - 1 ? 8 * c + 5 : ND - 1;  // last value of chunk c
+          for (int c = 0; c < PK_::NPC; ++c) {
+            constexpr int NDWc = PK_::NDW;
+            const int dlast = 4 * c + 3 < NDWc - 1 ? 4 * c + 3 : NDWc - 1;  // last lane-record dword of piece c
+            const int last = PK_::val(2 * dlast + 1);                        // ... and the last value it holds
             // (issued together after the last point: the packed sweep is bound by issue, not by the store queue -- spreading
             //  them over the step, which paid 6 % with full records, now costs 1-2.5 %: config-4 chunk 78.5 vs 76.5 ms)
             if ((BIALIGN_OPT & 4) ? bb == W - 1 : (last >= bb * 9 && last < (bb + 1) * 9)) {
@@ -639,15 +649,23 @@ __global__ void __launch_bounds__(64 * TW) fill_affine_kernel(const DeviceBatch 
 #pragma unroll
               for (int x = 0; x < 4; ++x) {
                 const int d = 4 * c + x;  // dword of the lane record
-                const int lo = 2 * d - 2, hi = 2 * d - 1;
+                const int lo = d < NDWc ? PK_::val(2 * d) : 0, hi = d < NDWc ? PK_::val(2 * d + 1) : 0;
                 // low halves of two offsets into one dword: one v_perm_b32
                 dw[x] = d == 0 ? pk_base
-                               : (int)__builtin_amdgcn_perm((unsigned)(hi < ND ? pk_e[PACK && hi < ND ? hi : 0] : 0),
-                                                            (unsigned)(lo < ND ? pk_e[PACK && lo < ND ? lo : 0] : 0), 0x05040100u);
+                               : (d < NDWc ? (int)__builtin_amdgcn_perm((unsigned)pk_e[PACK ? hi : 0], (unsigned)pk_e[PACK ? lo : 0], 0x05040100u) : 0);
               }
-              v4i v;
-              v.x = dw[0]; v.y = dw[1]; v.z = dw[2]; v.w = dw[3];
-              store_chunk<XCU>(dstp + c * R_::CH + slot * 4, v, wt_lane);
+              if (c < PK_::NCH) {
+                v4i v;
+                v.x = dw[0]; v.y = dw[1]; v.z = dw[2]; v.w = dw[3];
+                store_chunk<XCU>(dstp + c * R_::CH + slot * 4, v, wt_lane);
+              } else if (slot < PK_::TSLOTS) {  // the tail piece: TAILDW dwords per lane
+                int32_t* tp = dstp + PK_::NCH * R_::CH + slot * PK_::TAILDW;
+#pragma unroll
+                for (int x = 0; x < PK_::TAILDW; ++x) {
+                  if (XCU && wt_lane) __hip_atomic_store(tp + x, dw[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                  else tp[x] = dw[x];
+                }
+              }
             }
           }
         }
@@ -754,24 +772,19 @@ __global__ void __launch_bounds__(64 * TW) fill_affine_kernel(const DeviceBatch 
       for (int u = 0; u < 3; ++u) h2y[u] = H2[u][0];
 
       // delay lines: index bb (bb-1 for GXM/GXX) has served its last consumer of this step
-      dmov(dA2[0][bb], dA1[0][bb]);
-      dmov(dA2[1][bb], dA1[1][bb]);
-      dmov(dA1[0][bb], inA[bb][0]);
-      dmov(dA1[1][bb], inA[bb][1]);
-      dmov(dB[0][bb], inB[bb][0]);
-#pragma unroll
-      for (int v = 0; v < 3; ++v) dmov(dB[1 + v][bb], inB[bb][2 + v]);
+      dmov2(dA2[0][bb], dA2[1][bb], dA1[0][bb], dA1[1][bb]);
+      dmov2(dA1[0][bb], dA1[1][bb], inA[bb][0], inA[bb][1]);
+      dmov2(dB[0][bb], dB[1][bb], inB[bb][0], inB[bb][2]);
+      dmov2(dB[2][bb], dB[3][bb], inB[bb][3], inB[bb][4]);
       dC[0][bb] = inC[bb][0];
       dC[1][bb] = inC[bb][1];
       if (bb >= 1) {
-        dmov(dAx[0][bb >= 1 ? bb - 1 : 0], inA[bb >= 1 ? bb - 1 : 0][2]);
-        dmov(dAx[1][bb >= 1 ? bb - 1 : 0], inA[bb >= 1 ? bb - 1 : 0][3]);
-        if (BIALIGN_OPT & 8) read_lds(bb >= 1 ? bb - 1 : 0);  // row bb-1 has served this step: fetch what it holds for the next
+        dmov2(dAx[0][bb >= 1 ? bb - 1 : 0], dAx[1][bb >= 1 ? bb - 1 : 0], inA[bb >= 1 ? bb - 1 : 0][2], inA[bb >= 1 ? bb - 1 : 0][3]);
+        read_lds(bb >= 1 ? bb - 1 : 0);  // row bb-1 has served this step: fetch what it holds for the next
       }
     }
-    dmov(dAx[0][W - 1], inA[W - 1][2]);
-    dmov(dAx[1][W - 1], inA[W - 1][3]);
-    if (BIALIGN_OPT & 8) read_lds(W - 1);
+    dmov2(dAx[0][W - 1], dAx[1][W - 1], inA[W - 1][2], inA[W - 1][3]);
+    read_lds(W - 1);
 
     // ---- 6. advance
     ++jj;
@@ -781,7 +794,7 @@ __global__ void __launch_bounds__(64 * TW) fill_affine_kernel(const DeviceBatch 
       rec_base += (T - 1) * P;
       set_row(strip);
     }
-    if (BIALIGN_OPT & 16) {
+    {
       if (INTERIOR) {  // same row, next column, everything inside the molecule: the window slides by one, and the
         mu1n = s1[s1row + sbn];  // two codes it needs were fetched at the end of the step before
         if (!DENSE) {

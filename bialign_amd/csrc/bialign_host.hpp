@@ -103,6 +103,9 @@ struct bialign_batch {
   size_t lds_bytes = 0;                   // dynamic LDS of a one-wave workgroup
   size_t lds_base = 0, lds_per_wave = 0;  // team launches: lds_base + T * lds_per_wave
   size_t lds_diet8 = 0;                   // eight-wave workgroups of the s=2 affine kernel (DIET layout)
+  // fill_affine_slim_kernel (bialign_fill_slim.hpp): twelve ghost rings + tables, and per pair of the workgroup its codes
+  size_t lds_slim_base = 0, lds_slim_codes = 0;
+  size_t lds_slim(int tw) const { return lds_slim_base + (size_t)(12 / tw) * lds_slim_codes; }
   size_t lds_trace = 0;                   // tracebacks: score tables + sequence codes
   DevBuf<PairDesc> d_pairs;
   DevBuf<int32_t> d_order, d_s1, d_s2, d_layers, d_scores, d_tlen, d_complete, d_err, d_prog;
@@ -176,8 +179,15 @@ namespace bialign {
 // One launch shape: TW waves per workgroup, GW workgroups per pair (GW > 1 = cross-CU team).
 struct TeamShape {
   int tw = 1, gw = 1;
+  bool slim = false;  // the three-waves-per-SIMD kernel (fill_affine_slim_kernel), workgroups of tw = 1, 2, 3, 6 or 12 waves
   int waves() const { return tw * gw; }
 };
+// fill_affine_slim_kernel exists for this batch: affine, max_shift 1, LOOKUP scores, beta <= 0, packed records, full storage
+inline bool slim_available(const bialign_batch* b) {
+  const char* sw = getenv("BIALIGN_SLIM");  // "0": tests / A-B, the two-wave kernels only
+  const bool off = sw && atoi(sw) == 0;
+  return !off && b->affine && b->S == 1 && !b->dense && !b->lean && !b->wide && b->prm.gap_opening_cost <= 0 && b->pack_now();
+}
 
 // xcu_resident: one-wave workgroups of the cross-CU kernel the device holds at once (0: no such kernel);
 // xcu8_resident: likewise its eight-wave workgroups (s=2 affine sweep only, else 0)
@@ -220,6 +230,39 @@ int launch_fill_affine_t(bialign_batch* b, const DeviceBatch& v, int first, int 
   return BIALIGN_OK;
 }
 
+template <int S, int TW>
+int launch_fill_affine_slim_t(bialign_batch* b, const DeviceBatch& v, int first, int count) {
+  constexpr int PPW = 12 / TW;  // pairs per twelve-wave workgroup
+  DeviceBatch w = v;
+  w.order = v.order + first;
+  w.team = 1;
+  w.launch_pairs = count;
+  w.slim_code_bytes = (int32_t)b->lds_slim_codes;
+  b->packed_layers = true;
+  b->used_pack = true;
+  auto kern = fill_affine_slim_kernel<S, TW, PPW>;
+  const size_t lds = b->lds_slim(TW);
+  if (lds > 64 * 1024)
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(kern, dim3((count + PPW - 1) / PPW), dim3(64 * 12), lds, b->eng->stream, w);
+  HIP_TRY(hipGetLastError());
+  return BIALIGN_OK;
+}
+
+template <int S>
+int launch_fill_affine_slim(bialign_batch* b, const DeviceBatch& v, int first, int count, int tw) {
+  if constexpr (S == 1) {
+    switch (tw) {
+      case 1: return launch_fill_affine_slim_t<S, 1>(b, v, first, count);
+      case 2: return launch_fill_affine_slim_t<S, 2>(b, v, first, count);
+      case 3: return launch_fill_affine_slim_t<S, 3>(b, v, first, count);
+      case 6: return launch_fill_affine_slim_t<S, 6>(b, v, first, count);
+      case 12: return launch_fill_affine_slim_t<S, 12>(b, v, first, count);
+    }
+  }
+  return fail(BIALIGN_E_UNSUPPORTED, "no three-waves-per-SIMD sweep for max_shift %d, team %d", S, tw);
+}
+
 // One-wave workgroups of the cross-CU kernel <S, LEAN> the device can hold at once, from the runtime's
 // occupancy calculation for the actual code object (registers, LDS): the cap of a cross-CU grid.
 template <int S, bool LEAN, int TW = 1, bool DENSE = false>
@@ -258,6 +301,9 @@ int launch_fill_affine_l(bialign_batch* b, const DeviceBatch& v, int first, int 
                                 : team_shape(b, first, count, xcu_ok ? xcu_resident_blocks<S, LEAN>(b) : 0,
                                              xcu_ok ? xcu_resident_blocks<S, LEAN, 8>(b) : 0);
   b->last_team = ts.waves() * (ts.gw > 1 ? -1 : 1);
+  if constexpr (!LEAN) {
+    if (ts.slim) return launch_fill_affine_slim<S>(b, v, first, count, ts.tw);
+  }
   if (b->dense) {  // dense-mu2 kernels: one-wave cross-CU teams, in-workgroup teams of 4 and 2, one wave
     if constexpr (S >= 1 && S <= BIALIGN_MAX_SHIFT_PACKED && !LEAN) {
       if (b->pack_now()) {

@@ -49,9 +49,20 @@
 #define BIALIGN_OPT 7  // 4 = packed records: all of a step's stores after its last point (one exec region instead of NCH)
 #endif
 
+#ifndef BIALIGN_OPT2  // round 3 instruction diet of the affine step (0: off, for A/B): gap-gap groups share their add; the
+#define BIALIGN_OPT2 1  // packer reuses the finalisation's "no valid case" test
+#endif
+
+#ifdef BIALIGN_WPE  // experiment: cap the affine sweep's registers so that this many waves fit a SIMD
+#define BIALIGN_WPE_ATTR __attribute__((amdgpu_waves_per_eu(BIALIGN_WPE, BIALIGN_WPE)))
+#else
+#define BIALIGN_WPE_ATTR
+#endif
+
 #include "bialign_types.hpp"
 #include "bialign_feed.hpp"
 #include "bialign_fill_affine.hpp"
+#include "bialign_fill_slim.hpp"
 #include "bialign_fill_linear.hpp"
 #include "bialign_wide.hpp"
 #include "bialign_traceback.hpp"

@@ -53,6 +53,8 @@ struct DeviceBatch {
   int32_t wide_s;       // wide-band path (max_shift beyond the tiled kernels): the band half-width
   int32_t prio_mode;    // 1 = rotate wave priorities by workgroup age (fill_affine_kernel); BIALIGN_PRIO=0 switches it off
   int32_t spin_limit;   // team hand-off: polls of the partner's progress word before a wave gives up (error flag)
+  int32_t launch_pairs;     // fill_affine_slim_kernel: pairs of this launch (a workgroup holds several)
+  int32_t slim_code_bytes;  // fill_affine_slim_kernel: LDS bytes of one pair's sequence and class codes
 };
 
 template <int S>
@@ -95,19 +97,22 @@ struct Rec {
 };
 
 // ---------------------------------------------------------------------------
-// Packed records (affine sweeps at max_shift 1 and 2, full storage).  In INTERIOR steps -- every lane's
+// Packed records (affine sweeps at max_shift 1..3, full storage).  In INTERIOR steps -- every lane's
 // lattice points have all four coordinates >= 1 and lie inside the molecule -- each of a lane's ND
 // layer values is either exactly -2^30 at one of six compile-time-known (state, b) positions
 // (can_be_empty<W>) or lies within a few thousand of the lane's first value, so the lane record shrinks
-// from ND dwords to  base + ND unsigned 16-bit offsets  (base = M[(1,1,1,1)] of the lane's first point
-// - 0x8000; offset 0xffff at a can_be_empty position = -2^30): 16 dwords instead of 27 at s=1, 24
-// instead of 45 at s=2.  The sweep verifies the range of every offset it stores; the first one that does
+// from ND dwords to  base + (ND - 1) unsigned 16-bit offsets  (base = M[(1,1,1,1)] of the lane's first
+// point - 0x8000, so THAT value's offset is 0x8000 by construction and is not stored; offset 0xffff at a
+// can_be_empty position = -2^30): 14 dwords instead of 27 at s=1 (round 2 stored all ND offsets: 16),
+// 23 instead of 45 at s=2, 32 instead of 63 at s=3.  The sweep verifies the range of every offset it stores; the first one that does
 // not fit raises the device flag and the host repeats the batch with full records.  All other steps
 // (strip changes, the first strip(s), the lattice border) keep full records in a second region of the
 // pair's storage.  Which steps are interior is a function of the record number alone, so readers
 // (ghost feed, tracebacks, dump) find a cell without any index:
 //   record r = Q*P + t,  t = j + 2*il + aa  (Q = strip of the lane, t may reach into the next period)
 //   phase c = r mod P, step-strip Qs = r div P;   interior  <=>  Qs >= Q0  and  LO <= c <= HI
+// Layout of a packed record: NCH chunks [chunk][slot][4 dwords] like a full record's, then -- where the
+// lane record is not a whole number of 16-byte chunks -- a tail [slot][TAILDW dwords].
 // ---------------------------------------------------------------------------
 // the six (state, band column) positions whose value can be exactly -2^30 in an interior step (= can_be_empty<W>)
 __host__ __device__ constexpr bool pack_corner(int W, int st, int bb) {
@@ -119,8 +124,23 @@ struct Pack {
   using G_ = Geo<S>;
   using R_ = Rec<S, 9>;
   static constexpr int ND = R_::ND;
-  static constexpr int NCH = (2 + ND + 7) / 8;        // 16-byte chunks of a packed lane record
-  static constexpr int RECDW = NCH * R_::CH;          // same [chunk][slot][4 dwords] shape as full records
+  static constexpr int ANCHOR = 8;                     // value index (band column 0, state (1,1,1,1)) the base is taken from
+  static constexpr int NHW = ND + 1;                   // halfwords of a lane record: base (2) + the other ND - 1 offsets
+  static constexpr int NDW = (NHW + 1) / 2;            // ... dwords
+  static constexpr int NCH = NDW / 4;                  // whole 16-byte chunks
+  static constexpr int TAILDW = NDW - 4 * NCH;         // dwords of the tail piece (s=1: 2, s=2: 3, s=3: 0)
+  static constexpr int NPC = NCH + (TAILDW ? 1 : 0);   // 16-byte pieces the ghost feed moves per lane record
+  // tail slots: the storing lanes', rounded up so that records stay 16-byte aligned
+  static constexpr int TSLOTS = TAILDW == 0 ? 0 : (TAILDW == 2 ? (R_::SL + 1) / 2 * 2 : (R_::SL + 3) / 4 * 4);
+  static constexpr int RECDW = NCH * R_::CH + TSLOTS * TAILDW;
+  static_assert(RECDW % 4 == 0, "packed records must stay 16-byte aligned");
+  // halfword of value v (v != ANCHOR) in the lane record, and the value a halfword h >= 2 holds
+  __host__ __device__ static constexpr int hw(int v) { return 2 + v - (v > ANCHOR ? 1 : 0); }
+  __host__ __device__ static constexpr int val(int h) { return h - 2 < ANCHOR ? h - 2 : h - 1; }
+  // dword offset of lane-record dword d of storage slot `slot` inside a packed record
+  __host__ __device__ static constexpr int dwpos(int slot, int d) {
+    return d < 4 * NCH ? (d >> 2) * R_::CH + slot * 4 + (d & 3) : NCH * R_::CH + slot * TAILDW + (d - 4 * NCH);
+  }
   static constexpr int LO = S + 1 + G_::MAXOFF;       // first phase at which every lane has passed column S
   static constexpr int Q0 = (S + 2 + G_::RR - 1) / G_::RR;  // first strip whose ghost row is row >= S+1
   __host__ __device__ static inline int hi(int m) { return m - S; }  // last phase whose points all lie inside the molecule
@@ -148,9 +168,11 @@ struct Pack {
   }
   // value (state st of band column bb) of a lane slot in a packed record at p
   __host__ __device__ static inline int decode(const int32_t* p, int slot, int bb, int st, bool corner) {
-    const int h = 2 + bb * 9 + st, dw = h >> 1;
+    const int v = bb * 9 + st;
     const int base = p[slot * 4];  // both loads issued together: one memory round trip per cell
-    const uint32_t word = (uint32_t)p[(dw >> 2) * R_::CH + slot * 4 + (dw & 3)];
+    if (v == ANCHOR) return base + 0x8000;
+    const int h = hw(v);
+    const uint32_t word = (uint32_t)p[dwpos(slot, h >> 1)];
     const uint32_t e = (h & 1) ? word >> 16 : word & 0xffffu;
     return (corner && e == 0xffffu) ? NEG : base + (int)e;
   }
