@@ -217,7 +217,6 @@ __global__ void __launch_bounds__(64 * TW) BIALIGN_WPE_ATTR fill_affine_kernel(c
   // ---- team protocol (T > 1): partner progress needed before prefetching the ghost
   //      block whose last local step is h_last
   int blk_q = 0, blk_rem = 0;  // (next block start) div / mod P
-  bool team_failed = false;
   // Cross-CU teams of multi-wave workgroups: only the last wave of a workgroup hands over to another CU
   // (its successor is wave 0 of the next workgroup): it alone writes through and publishes its progress in
   // HBM; the others meet their successor in this workgroup's LDS and L2, like an in-workgroup team.
@@ -237,9 +236,9 @@ __global__ void __launch_bounds__(64 * TW) BIALIGN_WPE_ATTR fill_affine_kernel(c
     else
       prog_lds[XCU ? wl : w] = v;
   };
-  int seen_prog = -0x40000000;  // the partner's progress as last read
+  int seen_prog = -0x40000000;  // the partner's progress as last read (INT_MAX once a hand-off has timed out: no further waits)
   auto wait_partner = [&](int h_last) __attribute__((always_inline)) {
-    if ((!XCU && TW == 1) || T == 1 || team_failed || BIALIGN_EXP == 9) return;  // 9: timing experiment, no hand-off waits
+    if ((!XCU && TW == 1) || T == 1 || BIALIGN_EXP == 9) return;  // 9: timing experiment, no hand-off waits
     const int src = w == 0 ? T - 1 : w - 1;
     const int need = h_last + 2 * (R - 1) + 1 - (w == 0 ? P : 0);
     // progress only grows: what was seen last time usually covers this block too, and a look at
@@ -249,7 +248,7 @@ __global__ void __launch_bounds__(64 * TW) BIALIGN_WPE_ATTR fill_affine_kernel(c
     for (int spin = 0; (seen_prog = prog_get(src)) < need; ++spin) {
       if (spin > A.spin_limit) {  // ~1 s by default; then fail fast: no further waits, the host recovers or reports
         if (L == 0) atomicOr(A.errflag, 1);
-        team_failed = true;
+        seen_prog = 0x7fffffff;
         break;
       }
       __builtin_amdgcn_s_sleep(16);
@@ -278,6 +277,7 @@ __global__ void __launch_bounds__(64 * TW) BIALIGN_WPE_ATTR fill_affine_kernel(c
   prefetch_block(0, 0, jj);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   int vm_younger = 0;  // store instructions issued since the last block's DMAs (wave-uniform)
+  int pk_all = 0;      // packed records: OR of every offset this lane has stored since the last range check
 
   // Exchange inputs of rows i-1 (what lanes L-W, L-W+1 published for each band column).  They are loop-carried:
   // row r is fetched from the exchange array at the END of a step, as soon as its last consumer of that step is
@@ -336,6 +336,11 @@ __global__ void __launch_bounds__(64 * TW) BIALIGN_WPE_ATTR fill_affine_kernel(c
       // the DMAs just retired were issued at step g - BLK ahead of that step's stores, and vmcnt retires in
       // order: the stores of all steps before g - BLK are acknowledged
       if ((XCU || TW > 1) && L == 0) prog_put(g - GF::BLK);
+      if (PACK) {  // an offset of the last block that does not fit 16 bits (or collides with the -2^30 mark): the host falls back
+        const bool bad = live && !ghost && (unsigned)pk_all > 0xffffu;
+        if (__builtin_amdgcn_ballot_w64(bad) != 0 && L == 0) atomicOr(A.errflag, 2);
+        pk_all = 0;
+      }
       if (PACK && PK_COOP) {
         // The block that has just landed holds, per (step t, band row a), the ghost row's source as it lies in
         // HBM: a packed lane record if that step of the strip above was interior (record phase c + 2(R-1)), else
@@ -416,7 +421,8 @@ __global__ void __launch_bounds__(64 * TW) BIALIGN_WPE_ATTR fill_affine_kernel(c
       // against the lane's cap (the sentinel where a-1 leaves the band, INT_MAX elsewhere).  One asm
       // block per band column: the compiler's own DPP folding gives up once the consumers are sunk
       // behind the store branches.  s_nop 1 = the two wait states a DPP read needs after a VALU write
-      // of its source (the hazard recogniser does not look inside asm); lane 0 reads out of range -> 0
+      // of its source (the hazard recogniser does not look inside asm; dropping it "because the sources are a
+      // step old" broke the dense s=2,3 kernels in round 3); lane 0 reads out of range -> 0
       // with bound_ctrl, it is an a_first lane anyway.  H2[.][M] (x = 2..4) of the last band column has
       // no consumer: offset (0,0,M) from there would leave the band.
       if (BIALIGN_OPT & 1) {
@@ -487,7 +493,8 @@ __global__ void __launch_bounds__(64 * TW) BIALIGN_WPE_ATTR fill_affine_kernel(c
                           (INTERIOR || __builtin_amdgcn_ballot_w64(tile_act && !ghost) != 0) &&
                           ((!XCU && TW == 1) || rec <= rec_last);
     const int slot = LEAN ? aa : (pad_lane ? R_::SL + pad_idx : L - W);  // storage slot of this lane
-    if (__builtin_amdgcn_ballot_w64(do_store) != 0) vm_younger += (PACK && INTERIOR) ? PK_::NPC : GF::STORES_PER_STEP;
+    if (INTERIOR && BIALIGN_EXP != 1) vm_younger += PACK ? PK_::NPC : GF::STORES_PER_STEP;  // (an interior step always stores)
+    else if (__builtin_amdgcn_ballot_w64(do_store) != 0) vm_younger += GF::STORES_PER_STEP;
     int32_t* dst = BIALIGN_EXP == 2
                        ? A.layers + ((int64_t)(blockIdx.x & 255) << 18) + (int64_t)(g & 31) * RECDW
                        : sto + (int64_t)rec * RECDW;
@@ -500,7 +507,7 @@ __global__ void __launch_bounds__(64 * TW) BIALIGN_WPE_ATTR fill_affine_kernel(c
 
     // ---- 3. the W lattice points of this (i, j, a)
     int outv[ND];
-    int pk_base = 0, pk_acc = 0, pk_e[PACK ? ND : 1];  // packed records: base, OR of the stored offsets, the offsets
+    int pk_base = 0, pk_acc = pk_all, pk_e[PACK ? ND : 1];  // packed records: base, OR of the stored offsets (running on across a block), the offsets
     int h2y[3] = {SENT, SENT, SENT};  // H2[U][Y] of point bb-1 (same step, same lane)
 #pragma unroll
     for (int bb = 0; bb < W; ++bb) {
@@ -669,13 +676,7 @@ __global__ void __launch_bounds__(64 * TW) BIALIGN_WPE_ATTR fill_affine_kernel(c
             }
           }
         }
-        if (bb == W - 1) {  // an offset that does not fit 16 bits (or collides with the -2^30 mark): the host falls back
-          const bool bad = act_row && !ghost && live && (unsigned)pk_acc > 0xffffu;
-#ifdef BIALIGN_DEBUG_PACK
-          if (bad) printf("pack overflow: pair %d step %d lane %d row %d col %d k %d acc %x base %d M8 %d n %d m %d\n", pid, g, L, i, jj, i + aa - S, pk_acc, pk_base, M[8], n, m);
-#endif
-          if (__builtin_amdgcn_ballot_w64(bad) != 0 && L == 0) atomicOr(A.errflag, 2);
-        }
+        if (bb == W - 1) pk_all = act_row ? pk_acc : 0;  // rows outside the lattice hold don't-care values; range-checked once per block
       }
       if (do_store && !(PACK && INTERIOR)) {
 #pragma unroll
@@ -788,7 +789,7 @@ __global__ void __launch_bounds__(64 * TW) BIALIGN_WPE_ATTR fill_affine_kernel(c
 
     // ---- 6. advance
     ++jj;
-    if (!RESW && jj == P) {  // a re-sweep ends inside its one strip
+    if (!RESW && !INTERIOR && jj == P) {  // a re-sweep ends inside its one strip; an interior step never ends a strip (phase <= m - S)
       jj = 0;
       ++strip;
       rec_base += (T - 1) * P;
@@ -831,6 +832,7 @@ __global__ void __launch_bounds__(64 * TW) BIALIGN_WPE_ATTR fill_affine_kernel(c
       ++g;
     }
   }
+  if (PACK && __builtin_amdgcn_ballot_w64(live && !ghost && (unsigned)pk_all > 0xffffu) != 0 && L == 0) atomicOr(A.errflag, 2);
   if (XCU || TW > 1) {  // everything this wave wrote is acknowledged: release the partner for good
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (L == 0) prog_put(0x7fffffff);

@@ -142,17 +142,16 @@ __global__ void __launch_bounds__(64 * TW * PPW, 3) fill_affine_slim_kernel(cons
 
   // ---- team protocol (as fill_affine_kernel, in-workgroup form)
   int blk_q = 0, blk_rem = 0;  // (next block start) div / mod P
-  bool team_failed = false;
-  int seen_prog = -0x40000000;
+  int seen_prog = -0x40000000;  // the partner's progress as last read (INT_MAX once a hand-off has timed out: no further waits)
   auto wait_partner = [&](int h_last) __attribute__((always_inline)) {
-    if (T == 1 || team_failed) return;
+    if (T == 1) return;
     const int src = w == 0 ? T - 1 : w - 1;
     const int need = h_last + 2 * (R - 1) + 1 - (w == 0 ? P : 0);
     if (seen_prog >= need) return;
     for (int spin = 0; (seen_prog = prog_lds[src]) < need; ++spin) {
       if (spin > A.spin_limit) {
         if (L == 0) atomicOr(A.errflag, 1);
-        team_failed = true;
+        seen_prog = 0x7fffffff;
         break;
       }
       __builtin_amdgcn_s_sleep(16);
@@ -171,6 +170,7 @@ __global__ void __launch_bounds__(64 * TW * PPW, 3) fill_affine_slim_kernel(cons
   prefetch_block(0, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   int vm_younger = 0;
+  int pk_all = 0;  // OR of every offset this lane has stored since the last range check
 
   // delay-line stage, opaque to the compiler (see fill_affine_kernel)
   auto dmov = [](int& dst, int src) __attribute__((always_inline)) { asm("v_mov_b32 %0, %1" : "=v"(dst) : "v"(src)); };
@@ -199,6 +199,11 @@ __global__ void __launch_bounds__(64 * TW * PPW, 3) fill_affine_slim_kernel(cons
     if (gt == 0) {
       GF::wait_block(vm_younger);
       if (TW > 1 && L == 0) prog_lds[w] = g - GF::BLK;
+      {  // an offset of the last block that does not fit 16 bits (or collides with the -2^30 mark): the host falls back
+        const bool bad = live && !ghost && (unsigned)pk_all > 0xffffu;  // (lanes that hold lattice points in interior steps)
+        if (__builtin_amdgcn_ballot_w64(bad) != 0 && L == 0) atomicOr(A.errflag, 2);
+        pk_all = 0;
+      }
       {  // the block that has just landed: lane t*W + a unpacks its entry in place (fill_affine_kernel, PK_COOP)
         const int c0 = __builtin_amdgcn_readfirstlane(jj), q0 = __builtin_amdgcn_readfirstlane(strip);
         if (L < GF::BLK * W) {
@@ -245,7 +250,8 @@ __global__ void __launch_bounds__(64 * TW * PPW, 3) fill_affine_slim_kernel(cons
     const int32_t* const gsrc = live ? reinterpret_cast<const int32_t*>(ring + ghalf * GF::SLOTS + (gt * W + aa) * GF::NP)
                                      : sentblk;
 
-    // ---- 1. lane L-1 = (i, a-1) hands its values over in registers: DPP wave shift fused with the cap
+    // ---- 1. lane L-1 = (i, a-1) hands its values over in registers: DPP wave shift fused with the cap (s_nop 1: the
+    //         wait states a DPP read needs, see fill_affine_kernel)
     int inC[W][8];
     auto read_dpp = [&](int r) __attribute__((always_inline)) {
       if (r + 1 < W) {
@@ -293,7 +299,8 @@ __global__ void __launch_bounds__(64 * TW * PPW, 3) fill_affine_slim_kernel(cons
     const bool do_store = ((live && !ghost) || pad_lane) && (INTERIOR || __builtin_amdgcn_ballot_w64(tile_act && !ghost) != 0) &&
                           (TW == 1 || rec <= rec_last);
     const int slot_ = pad_lane ? R_::SL + pad_idx : L - W;
-    if (__builtin_amdgcn_ballot_w64(do_store) != 0) vm_younger += INTERIOR ? PK_::NPC : GF::STORES_PER_STEP;
+    if (INTERIOR) vm_younger += PK_::NPC;  // (an interior step always stores)
+    else if (__builtin_amdgcn_ballot_w64(do_store) != 0) vm_younger += GF::STORES_PER_STEP;
     int32_t* dst = lay;  // boundary steps: the full record in the pair's second region, by (step-strip, phase)
     int32_t* const dstp = lay + (int64_t)rec * PK_::RECDW;  // interior steps: the packed record
     if (!INTERIOR) {
@@ -304,7 +311,7 @@ __global__ void __launch_bounds__(64 * TW * PPW, 3) fill_affine_slim_kernel(cons
 
     // ---- 3. the W lattice points of this (i, j, a)
     int outv[INTERIOR ? 1 : ND];
-    int pk_base = 0, pk_acc = 0, pk_e[INTERIOR ? ND : 1];
+    int pk_base = 0, pk_acc = pk_all, pk_e[INTERIOR ? ND : 1];  // (the OR of the offsets runs on across the steps of a block)
     int h2y[3] = {SENT, SENT, SENT};
     int defer[3] = {SENT, SENT, SENT};  // GXM, GXX, GXY of the previous point: their registers are busy for one more point
 #pragma unroll
@@ -447,10 +454,7 @@ __global__ void __launch_bounds__(64 * TW * PPW, 3) fill_affine_slim_kernel(cons
             }
           }
         }
-        if (bb == W - 1) {  // an offset that does not fit 16 bits (or collides with the -2^30 mark): the host falls back
-          const bool bad = act_row && !ghost && live && (unsigned)pk_acc > 0xffffu;
-          if (__builtin_amdgcn_ballot_w64(bad) != 0 && L == 0) atomicOr(A.errflag, 2);
-        }
+        if (bb == W - 1) pk_all = act_row ? pk_acc : 0;  // rows outside the lattice hold don't-care values; range-checked once per block
       } else {
         if (do_store) {
 #pragma unroll
@@ -545,7 +549,7 @@ __global__ void __launch_bounds__(64 * TW * PPW, 3) fill_affine_slim_kernel(cons
 
     // ---- advance
     ++jj;
-    if (jj == P) {
+    if (!INTERIOR && jj == P) {  // (an interior step never ends a strip: its phase is at most m - S)
       jj = 0;
       ++strip;
       rec_base += (T - 1) * P;
@@ -572,11 +576,13 @@ __global__ void __launch_bounds__(64 * TW * PPW, 3) fill_affine_slim_kernel(cons
       step(BoolTag<false>{}, g);
       ++g;
     }
+    // (a run counted once instead of tested per step makes hipcc spill 74 registers here, as it did in fill_affine_kernel)
     while (g < H && all_interior()) {
       step(BoolTag<true>{}, g);
       ++g;
     }
   }
+  if (__builtin_amdgcn_ballot_w64(live && !ghost && (unsigned)pk_all > 0xffffu) != 0 && L == 0) atomicOr(A.errflag, 2);
   if (TW > 1) {  // everything this wave wrote is acknowledged: release the partner for good
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (L == 0) prog_lds[w] = 0x7fffffff;
