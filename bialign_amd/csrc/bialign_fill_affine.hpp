@@ -285,6 +285,10 @@ __global__ void __launch_bounds__(64 * TW) BIALIGN_WPE_ATTR fill_affine_kernel(c
   // of standing at the head of the next one.  Likewise the score inputs of the next column: the two dependent LDS
   // reads (code byte, then table entry) leave the head of the step (-1 % fill time at len 1024; the sweep is bound by
   // VALU issue, profiles/r03a_headline_baseline).
+  // Both early fetches cost registers (12 W for the exchange inputs, W + 3 for the scores): at max_shift >= 2 the
+  // eight-wave kernels (256 registers) spill with them and config 4 ran at half speed -- there the rows are read at
+  // the head of the step, two band columns ahead of use, as in round 2.
+  constexpr bool PREF = S <= 1;
   int inA[W][4], inB[W][8];
   auto read_lds = [&](int r) __attribute__((always_inline)) {
 #pragma unroll
@@ -296,7 +300,10 @@ __global__ void __launch_bounds__(64 * TW) BIALIGN_WPE_ATTR fill_affine_kernel(c
   // register the next fetch wants, and the allocator then copies the freshly fetched values at the back-edge instead
   // -- behind an lgkmcnt wait, which is the stall the early fetch was to hide.  (Moving two stages as one register
   // pair buys nothing: on gfx950 v_mov_b64 costs a SIMD 4.3 cycles, two v_mov_b32 4.8 -- tools/valu_rate.hip.)
-  auto dmov = [](int& dst, int src) __attribute__((always_inline)) { asm("v_mov_b32 %0, %1" : "=v"(dst) : "v"(src)); };
+  auto dmov = [](int& dst, int src) __attribute__((always_inline)) {
+    if (PREF) asm("v_mov_b32 %0, %1" : "=v"(dst) : "v"(src));
+    else dst = src;
+  };
   auto dmov2 = [&](int& d0, int& d1, int s0, int s1) __attribute__((always_inline)) {
     dmov(d0, s0);
     dmov(d1, s1);
@@ -308,8 +315,10 @@ __global__ void __launch_bounds__(64 * TW) BIALIGN_WPE_ATTR fill_affine_kernel(c
 #pragma unroll
     for (int bb = 0; bb < W; ++bb) mu2n[bb] = DENSE ? 0 : s2[s2row + cb[jc + bb]];  // l-1+PADB = jc+bb
   };
+  if (PREF) {
 #pragma unroll
-  for (int r = 0; r < W; ++r) read_lds(r);
+    for (int r = 0; r < W; ++r) read_lds(r);
+  }
   // ... and, one step further ahead, the two codes an interior step's end looks up (column jj + 1 of the same row)
   int sbn = 0, cbn = 0;
   auto fetch_codes = [&]() __attribute__((always_inline)) {
@@ -317,8 +326,10 @@ __global__ void __launch_bounds__(64 * TW) BIALIGN_WPE_ATTR fill_affine_kernel(c
     sbn = sb[jc1 - 1 + PADB];
     cbn = DENSE ? 0 : cb[jc1 + W - 1];
   };
-  lookup_mu();
-  fetch_codes();
+  if (PREF) {
+    lookup_mu();
+    fetch_codes();
+  }
 
   // One step of the sweep.  INTERIOR steps (every lane's lattice points have all
   // four coordinates >= 1 and lie inside the molecule columns; ~90 % of the
@@ -417,6 +428,7 @@ __global__ void __launch_bounds__(64 * TW) BIALIGN_WPE_ATTR fill_affine_kernel(c
     //         (all of them up front for W <= 3): a sliding window keeps registers flat in W.
     int inC[W][8];
     auto read_rows = [&](int r) __attribute__((always_inline)) {
+      if (!PREF) read_lds(r);
       // lane L-1 = (i, a-1) hands its values over in registers: one DPP wave shift fused with a min
       // against the lane's cap (the sentinel where a-1 leaves the band, INT_MAX elsewhere).  One asm
       // block per band column: the compiler's own DPP folding gives up once the consumers are sunk
@@ -463,7 +475,8 @@ __global__ void __launch_bounds__(64 * TW) BIALIGN_WPE_ATTR fill_affine_kernel(c
     if (W > 1) read_rows(W > 1 ? 1 : 0);
 
     // ---- 2. score inputs of this column (pyx:260-261; LOOKUP form)
-    const int mu1 = mu1n;
+    const int jc = INTERIOR ? jj : min(max(jj, 0), m + 1);
+    const int mu1 = PREF ? mu1n : s1[s1row + sb[jc - 1 + PADB]];
     int mu2[W];
     if (DENSE) {  // slide the window, take this step's new value from the ring
 #pragma unroll
@@ -471,9 +484,12 @@ __global__ void __launch_bounds__(64 * TW) BIALIGN_WPE_ATTR fill_affine_kernel(c
       mu2w[W - 1] = mu2ring[(ghalf * MF::BLK + gt) * 64 + L];
 #pragma unroll
       for (int bb = 0; bb < W; ++bb) mu2[bb] = mu2w[bb];
-    } else {
+    } else if (PREF) {
 #pragma unroll
       for (int bb = 0; bb < W; ++bb) mu2[bb] = mu2n[bb];
+    } else {
+#pragma unroll
+      for (int bb = 0; bb < W; ++bb) mu2[bb] = s2[s2row + cb[jc + bb]];  // l-1+PADB = jc+bb
     }
 
     const bool tile_act = INTERIOR ? true : (act_row && jj >= 0 && jj <= m);
@@ -781,11 +797,11 @@ __global__ void __launch_bounds__(64 * TW) BIALIGN_WPE_ATTR fill_affine_kernel(c
       dC[1][bb] = inC[bb][1];
       if (bb >= 1) {
         dmov2(dAx[0][bb >= 1 ? bb - 1 : 0], dAx[1][bb >= 1 ? bb - 1 : 0], inA[bb >= 1 ? bb - 1 : 0][2], inA[bb >= 1 ? bb - 1 : 0][3]);
-        read_lds(bb >= 1 ? bb - 1 : 0);  // row bb-1 has served this step: fetch what it holds for the next
+        if (PREF) read_lds(bb >= 1 ? bb - 1 : 0);  // row bb-1 has served this step: fetch what it holds for the next
       }
     }
     dmov2(dAx[0][W - 1], dAx[1][W - 1], inA[W - 1][2], inA[W - 1][3]);
-    read_lds(W - 1);
+    if (PREF) read_lds(W - 1);
 
     // ---- 6. advance
     ++jj;
@@ -795,7 +811,7 @@ __global__ void __launch_bounds__(64 * TW) BIALIGN_WPE_ATTR fill_affine_kernel(c
       rec_base += (T - 1) * P;
       set_row(strip);
     }
-    {
+    if (PREF) {
       if (INTERIOR) {  // same row, next column, everything inside the molecule: the window slides by one, and the
         mu1n = s1[s1row + sbn];  // two codes it needs were fetched at the end of the step before
         if (!DENSE) {

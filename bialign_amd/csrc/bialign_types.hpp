@@ -104,7 +104,7 @@ struct Rec {
 // from ND dwords to  base + (ND - 1) unsigned 16-bit offsets  (base = M[(1,1,1,1)] of the lane's first
 // point - 0x8000, so THAT value's offset is 0x8000 by construction and is not stored; offset 0xffff at a
 // can_be_empty position = -2^30): 14 dwords instead of 27 at s=1 (round 2 stored all ND offsets: 16),
-// 23 instead of 45 at s=2, 32 instead of 63 at s=3.  The sweep verifies the range of every offset it stores; the first one that does
+// 24 instead of 45 at s=2, 32 instead of 63 at s=3 (36 in round 2).  The sweep verifies the range of every offset it stores; the first one that does
 // not fit raises the device flag and the host repeats the batch with full records.  All other steps
 // (strip changes, the first strip(s), the lattice border) keep full records in a second region of the
 // pair's storage.  Which steps are interior is a function of the record number alone, so readers
@@ -127,8 +127,11 @@ struct Pack {
   static constexpr int ANCHOR = 8;                     // value index (band column 0, state (1,1,1,1)) the base is taken from
   static constexpr int NHW = ND + 1;                   // halfwords of a lane record: base (2) + the other ND - 1 offsets
   static constexpr int NDW = (NHW + 1) / 2;            // ... dwords
-  static constexpr int NCH = NDW / 4;                  // whole 16-byte chunks
-  static constexpr int TAILDW = NDW - 4 * NCH;         // dwords of the tail piece (s=1: 2, s=2: 3, s=3: 0)
+  // whole 16-byte chunks, and a tail piece of TAILDW dwords per lane: 8 bytes at s=1 (14 dwords = 3 chunks + 2), none
+  // at s=3 (32 dwords); a 12-byte tail (s=2: 23 dwords) is rounded up to a chunk -- three scalar dword stores per
+  // lane (write-through ones in cross-CU teams) cost far more than the four bytes (config 4: 329 vs 165 ms)
+  static constexpr int NCH = NDW / 4 + (NDW % 4 == 3 ? 1 : 0);
+  static constexpr int TAILDW = NDW % 4 == 3 ? 0 : NDW % 4;
   static constexpr int NPC = NCH + (TAILDW ? 1 : 0);   // 16-byte pieces the ghost feed moves per lane record
   // tail slots: the storing lanes', rounded up so that records stay 16-byte aligned
   static constexpr int TSLOTS = TAILDW == 0 ? 0 : (TAILDW == 2 ? (R_::SL + 1) / 2 * 2 : (R_::SL + 3) / 4 * 4);
