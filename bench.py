@@ -94,17 +94,23 @@ def run_steps(batch, count, gather, npairs_total):
     return acc
 
 
+VALU_CYCLES = 4  # SIMD cycles one wave64 VALU instruction of this sweep occupies: SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU is
+# exactly one quad-cycle in every pass kept under profiles/, and the sweep's time follows its instruction count, not its
+# occupancy (2 or 3 waves per SIMD) nor its bytes (tools/valu_rate.hip has the per-instruction rates)
+
+
 def roofline(info, fill_ms, launches, key):
     """`achieved` = ALGORITHMIC bytes (36 B per DP cell) of one fill launch / its average
     duration (HIP events on the engine's stream).  Beside it, from the committed rocprofv3 counter passes of the same
     launch shape (profiles/hbm_traffic.json names the directory): `traffic` = FETCH_SIZE + WRITE_SIZE bytes per launch,
     `traffic_frac` = that / launch time / 8 TB/s (what the memory system really moves), `issue` = VALU
-    wave-instructions x 2 cycles (a wave64 VALU instruction occupies a SIMD-32 for two) / (SIMDs x clock x launch
-    time); `bound` names the largest of the three fractions."""
+    wave-instructions x 4 cycles / (1024 SIMDs x GUI-active cycles of the profiled launch) -- the fraction of the SIMDs'
+    vector-issue capacity the sweep uses (`issue_2cyc`: the same at the 2 cycles a wave64 instruction would take if two
+    waves' instructions overlapped perfectly, which this instruction mix does not do); `bound_detail` names the largest."""
     fill_avg_ms = fill_ms / max(launches, 1)                  # average fill-kernel launch
     bytes_per_launch = info["layer_bytes"] / info["nchunks"]  # 36 B x cells of one launch
     achieved = bytes_per_launch / (fill_avg_ms * 1e-3) / 1e9
-    out = {"bound": "hbm", "kernel": "fill_affine_kernel", "achieved": achieved, "peak": HBM_PEAK_GBPS,
+    out = {"bound": "hbm", "kernel": "fill_affine_slim_kernel / fill_affine_kernel", "achieved": achieved, "peak": HBM_PEAK_GBPS,
            "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None, "traffic_source": None,
            "bytes_per_launch": bytes_per_launch, "avg_launch_ms": fill_avg_ms}
     tpath = os.path.join(REPO, "profiles", "hbm_traffic.json")
@@ -114,13 +120,14 @@ def roofline(info, fill_ms, launches, key):
         if entry:
             out["traffic"], out["traffic_source"] = entry["bytes_per_launch"], entry["profile"]
             out["traffic_frac"] = entry["bytes_per_launch"] / (fill_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS
-            if entry.get("valu_wave_insts_per_launch"):
-                simds, clock = 1024, entry.get("clock_ghz", 2.4) * 1e9
-                out["issue"] = entry["valu_wave_insts_per_launch"] * 2 / (simds * clock * fill_avg_ms * 1e-3)
-                out["issue_source"] = f"SQ_INSTS_VALU {entry['valu_wave_insts_per_launch']:.4g} per launch, " \
-                                      f"clock {entry.get('clock_ghz', 2.4)} GHz ({entry['profile']})"
-            fr = {"hbm (algorithmic bytes)": out["frac"], "hbm (measured traffic)": out["traffic_frac"],
-                  "valu issue": out.get("issue", 0.0)}
+            fr = {"hbm (measured traffic)": out["traffic_frac"]}  # physical limits only; `frac` is the section 8d yardstick
+            if entry.get("valu_wave_insts_per_launch") and entry.get("gui_active_cycles_per_launch"):
+                simd_cycles = 1024 * entry["gui_active_cycles_per_launch"]
+                out["issue"] = entry["valu_wave_insts_per_launch"] * VALU_CYCLES / simd_cycles
+                out["issue_2cyc"] = entry["valu_wave_insts_per_launch"] * 2 / simd_cycles
+                out["issue_source"] = (f"SQ_INSTS_VALU {entry['valu_wave_insts_per_launch']:.4g} x {VALU_CYCLES} cycles / (1024 SIMDs x "
+                                       f"GRBM_GUI_ACTIVE/8 = {entry['gui_active_cycles_per_launch']:.4g} cycles), both of the profiled launch")
+                fr["valu issue"] = out["issue"]
             out["bound_detail"] = max(fr, key=fr.get)
     return out
 

@@ -61,14 +61,33 @@ TeamShape team_shape(const bialign_batch* b, int first, int count, int xcu_resid
 
   const char* e = getenv("BIALIGN_TEAM");  // experiments / tests: "N" in-workgroup, "xN" cross-CU, "hN" N eight-wave workgroups
   if (e && !*e) e = nullptr;
-  // The three-waves-per-SIMD sweep (fill_affine_slim_kernel: 168 registers, no exchange array): workgroups of 1, 2, 3, 6
-  // or 12 waves, always twelve waves per CU.  Taken whenever it keeps at least as many waves running as the two-wave
+  if (e && e[0] == 'x') {
+    ts.gw = std::max(1, std::min(atoi(e + 1), gw));
+    return ts;
+  }
+  if (e && e[0] == 'h') {
+    if (gw8 >= 1 && tw == 8) {
+      ts.tw = 8;
+      ts.gw = std::max(1, std::min(atoi(e + 1), gw8));
+    }
+    return ts;
+  }
+  // in-workgroup: the smallest team that (nearly) maximises the waves running at once, given
+  // how many workgroups of that size a CU holds (LDS, registers)
+  const int waves_cu_regs = !b->affine ? 16 : (b->S <= 1 ? 12 : (b->S == 2 ? 8 : 4));
+  auto concurrent = [&](int t) {
+    const size_t lds = (lds_of(t) + 1023) / 1024 * 1024;
+    const int wg_cu = (int)std::min<size_t>((160 * 1024) / lds, (size_t)(waves_cu_regs / t));
+    return std::min<int64_t>((int64_t)count * t, (int64_t)b->eng->num_cu * wg_cu * t);
+  };
+  // The three-waves-per-SIMD sweep (fill_affine_slim_kernel: 168 registers, no exchange array): teams of 2, 3, 6 or 12
+  // waves in workgroups of twelve, one per CU.  Taken whenever it keeps at least as many waves running as the two-wave
   // kernels' best shape -- a SIMD runs three such waves at the per-wave speed of two (tools/valu_rate.hip).
   if (slim_available(b) && !(e && (e[0] == 'x' || e[0] == 'h'))) {
     // a workgroup = 12 waves = (12 / t) pairs x teams of t, one per CU: every SIMD holds exactly three waves
     auto conc_slim = [&](int t) { return std::min<int64_t>((int64_t)count * t, (int64_t)b->eng->num_cu * 12); };
     auto fits = [&](int t) { return t <= fit_exact && b->lds_slim(t) <= 160 * 1024; };
-    static const int sizes[] = {1, 2, 3, 6, 12};
+    static const int sizes[] = {2, 3, 6, 12};  // (a one-wave team spills in hipcc's allocation: 168 registers + scratch)
     int pick = 0;
     if (e) {  // forced in-workgroup team: the slim kernel if it comes in that size
       const int want = atoi(e);
@@ -81,6 +100,9 @@ TeamShape team_shape(const bialign_batch* b, int first, int count, int xcu_resid
       for (int t : sizes)
         if (!pick && fits(t) && conc_slim(t) * 100 >= best_s * 95) pick = t;
     }
+    int64_t best_old = 0;  // what the two-wave kernels' in-workgroup teams keep running at best
+    for (int c = 1; c <= tw; c *= 2) best_old = std::max(best_old, concurrent(c));
+    if (pick && !e && conc_slim(pick) < best_old) pick = 0;  // (e.g. 256 pairs whose period admits teams of 6: 1536 waves against 2048)
     if (pick) {
       // (a handful of long pairs still go to cross-CU teams of the two-wave kernel below when that spreads them wider)
       const int64_t run_s = conc_slim(pick);
@@ -92,31 +114,12 @@ TeamShape team_shape(const bialign_batch* b, int first, int count, int xcu_resid
       }
     }
   }
-  if (e && e[0] == 'x') {
-    ts.gw = std::max(1, std::min(atoi(e + 1), gw));
-    return ts;
-  }
-  if (e && e[0] == 'h') {
-    if (gw8 >= 1 && tw == 8) {
-      ts.tw = 8;
-      ts.gw = std::max(1, std::min(atoi(e + 1), gw8));
-    }
-    return ts;
-  }
   if (e) {
     int want = atoi(e), t = 1;
     while (t * 2 <= want && t * 2 <= tw) t *= 2;
     ts.tw = t;
     return ts;
   }
-  // in-workgroup: the smallest team that (nearly) maximises the waves running at once, given
-  // how many workgroups of that size a CU holds (LDS, registers)
-  const int waves_cu_regs = !b->affine ? 16 : (b->S <= 1 ? 12 : (b->S == 2 ? 8 : 4));
-  auto concurrent = [&](int t) {
-    const size_t lds = (lds_of(t) + 1023) / 1024 * 1024;
-    const int wg_cu = (int)std::min<size_t>((160 * 1024) / lds, (size_t)(waves_cu_regs / t));
-    return std::min<int64_t>((int64_t)count * t, (int64_t)b->eng->num_cu * wg_cu * t);
-  };
   // Two-wave workgroups of the s=2 affine kernel (256 registers, two such workgroups per CU) measured
   // 20-35 % slower per pair than one- or four-wave ones at the same number of resident waves
   // (tools/team_table.sh; not so at s=1 or s=3), so that sweep goes 1 -> 4.

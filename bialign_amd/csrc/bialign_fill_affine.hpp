@@ -347,7 +347,7 @@ __global__ void __launch_bounds__(64 * TW) BIALIGN_WPE_ATTR fill_affine_kernel(c
       // the DMAs just retired were issued at step g - BLK ahead of that step's stores, and vmcnt retires in
       // order: the stores of all steps before g - BLK are acknowledged
       if ((XCU || TW > 1) && L == 0) prog_put(g - GF::BLK);
-      if (PACK) {  // an offset of the last block that does not fit 16 bits (or collides with the -2^30 mark): the host falls back
+      if (PACK && (g & 15) == 0) {  // every 16 steps: an offset since then that does not fit 16 bits (or collides with the -2^30 mark): the host falls back
         const bool bad = live && !ghost && (unsigned)pk_all > 0xffffu;
         if (__builtin_amdgcn_ballot_w64(bad) != 0 && L == 0) atomicOr(A.errflag, 2);
         pk_all = 0;

@@ -27,12 +27,15 @@
 
 namespace bialign {
 
-template <int S, int TW, int PPW>
+//   LEAN (score-only batches and the sweep of the memory-lean traceback): the step keeps only what the next strip's
+//   ghost row replays -- the bottom real row, as plain int32 records (Rec<S,9,true>) -- and the lane that computes
+//   (n,m,n,m) writes the score.  No stores to speak of, so this form is where the third wave pays most.
+template <int S, int TW, int PPW, bool LEAN = false>
 __global__ void __launch_bounds__(64 * TW * PPW, 3) fill_affine_slim_kernel(const DeviceBatch A) {
   static_assert(S >= 1, "packed records need a band");
   using PK_ = Pack<S>;
   using G_ = Geo<S>;
-  using R_ = Rec<S, 9, false>;
+  using R_ = Rec<S, 9, LEAN>;
   constexpr int W = G_::W, R = G_::R, RR = G_::RR, PADB = G_::PADB;
   constexpr int ND = R_::ND, NCH4 = R_::NCH4, TAIL = R_::TAIL, RECDW = R_::RECDW;
   static_assert(R * W < 64, "lane 63 must be free: it is the sentinel source of the exchange");
@@ -57,7 +60,7 @@ __global__ void __launch_bounds__(64 * TW * PPW, 3) fill_affine_slim_kernel(cons
   const int gD = gamma + delta, gg = 2 * gamma, ggdd = 2 * gamma + 2 * delta, dd = 2 * delta;
 
   // ---- LDS carve-up: per wave a ghost ring; shared: a block of sentinels, progress words, score tables; per pair its codes
-  using GF = GhostFeed<S, 9, false, 0>;
+  using GF = GhostFeed<S, 9, LEAN, 0>;
   constexpr int PERW = GF::RING_DW;
   constexpr int SENTBLK = 4 * GF::NP;                                 // one (step, a) entry worth of sentinels
   v4i* ring = reinterpret_cast<v4i*>(smem + wv * GF::RING_DW);        // ghost-row ring, two halves
@@ -163,7 +166,8 @@ __global__ void __launch_bounds__(64 * TW * PPW, 3) fill_affine_slim_kernel(cons
     //  for three rounds -- would otherwise be hoisted out of the sweep and sit in a dozen registers the step needs)
     int Lv = L;
     asm volatile("" : "+v"(Lv));
-    GF::issue_packed(lay, pk_bnd_off, m, h0, blk_q, blk_rem, P, T, w, rec_last, Lv, ring_lds + half * GF::SLOTS * 16);
+    if (LEAN) GF::issue(lay, h0, blk_q, blk_rem, P, T, w, P - 2 * (R - 1), rec_last, Lv, ring_lds + half * GF::SLOTS * 16);
+    else GF::issue_packed(lay, pk_bnd_off, m, h0, blk_q, blk_rem, P, T, w, rec_last, Lv, ring_lds + half * GF::SLOTS * 16);
     blk_rem += GF::BLK;
     if (blk_rem >= P) { blk_rem -= P; ++blk_q; }
   };
@@ -199,12 +203,12 @@ __global__ void __launch_bounds__(64 * TW * PPW, 3) fill_affine_slim_kernel(cons
     if (gt == 0) {
       GF::wait_block(vm_younger);
       if (TW > 1 && L == 0) prog_lds[w] = g - GF::BLK;
-      {  // an offset of the last block that does not fit 16 bits (or collides with the -2^30 mark): the host falls back
+      if (!LEAN && (g & 15) == 0) {  // every 16 steps: an offset since then that does not fit 16 bits (or collides with the -2^30 mark): the host falls back
         const bool bad = live && !ghost && (unsigned)pk_all > 0xffffu;  // (lanes that hold lattice points in interior steps)
         if (__builtin_amdgcn_ballot_w64(bad) != 0 && L == 0) atomicOr(A.errflag, 2);
         pk_all = 0;
       }
-      {  // the block that has just landed: lane t*W + a unpacks its entry in place (fill_affine_kernel, PK_COOP)
+      if (!LEAN) {  // the block that has just landed: lane t*W + a unpacks its entry in place (fill_affine_kernel, PK_COOP)
         const int c0 = __builtin_amdgcn_readfirstlane(jj), q0 = __builtin_amdgcn_readfirstlane(strip);
         if (L < GF::BLK * W) {
           const int t = L / W, ai = L - t * W;
@@ -296,22 +300,23 @@ __global__ void __launch_bounds__(64 * TW * PPW, 3) fill_affine_slim_kernel(cons
     const int rec = g + rec_base;
     const int pad_idx = L < W ? L : (L >= R * W ? W + (L - R * W) : 64);
     const bool pad_lane = pad_idx < R_::SLP - R_::SL;
-    const bool do_store = ((live && !ghost) || pad_lane) && (INTERIOR || __builtin_amdgcn_ballot_w64(tile_act && !ghost) != 0) &&
-                          (TW == 1 || rec <= rec_last);
-    const int slot_ = pad_lane ? R_::SL + pad_idx : L - W;
-    if (INTERIOR) vm_younger += PK_::NPC;  // (an interior step always stores)
+    constexpr bool PACKED = INTERIOR && !LEAN;  // this step writes a packed record
+    const bool do_store = ((live && (LEAN ? il == R - 1 : !ghost)) || (!LEAN && pad_lane)) &&
+                          (INTERIOR || __builtin_amdgcn_ballot_w64(tile_act && !ghost) != 0) && (TW == 1 || rec <= rec_last);
+    const int slot_ = LEAN ? aa : (pad_lane ? R_::SL + pad_idx : L - W);
+    if (INTERIOR) vm_younger += PACKED ? PK_::NPC : GF::STORES_PER_STEP;  // (an interior step always stores)
     else if (__builtin_amdgcn_ballot_w64(do_store) != 0) vm_younger += GF::STORES_PER_STEP;
-    int32_t* dst = lay;  // boundary steps: the full record in the pair's second region, by (step-strip, phase)
+    int32_t* dst = lay + (int64_t)rec * RECDW;  // LEAN: the one region; else (boundary steps) the full record in the pair's second region
     int32_t* const dstp = lay + (int64_t)rec * PK_::RECDW;  // interior steps: the packed record
-    if (!INTERIOR) {
+    if (!INTERIOR && !LEAN) {
       const int tl = jj + 2 * il + aa;
       const int over = tl >= P ? 1 : 0;
       dst = lay + pk_bnd_off + PK_::bidx(strip * T + w + over, tl - over * P, P, m) * RECDW;
     }
 
     // ---- 3. the W lattice points of this (i, j, a)
-    int outv[INTERIOR ? 1 : ND];
-    int pk_base = 0, pk_acc = pk_all, pk_e[INTERIOR ? ND : 1];  // (the OR of the offsets runs on across the steps of a block)
+    int outv[PACKED ? 1 : ND];
+    int pk_base = 0, pk_acc = pk_all, pk_e[PACKED ? ND : 1];  // (the OR of the offsets runs on across the steps of a block)
     int h2y[3] = {SENT, SENT, SENT};
     int defer[3] = {SENT, SENT, SENT};  // GXM, GXX, GXY of the previous point: their registers are busy for one more point
 #pragma unroll
@@ -406,10 +411,20 @@ __global__ void __launch_bounds__(64 * TW * PPW, 3) fill_affine_slim_kernel(cons
           M[q] = bad ? low : tv;
         }
         if (bb == S) M[8] = is_origin ? 0 : M[8];  // pyx:483-485
-#pragma unroll
-        for (int q = 0; q < 9; ++q) outv[INTERIOR ? 0 : bb * 9 + q] = M[q];
       }
-      if (INTERIOR) {
+      if (!PACKED) {
+#pragma unroll
+        for (int q = 0; q < 9; ++q) outv[PACKED ? 0 : bb * 9 + q] = M[q];
+      }
+      if (LEAN && bb == S) {  // score-only: the end cell (n,m,n,m) is all the host wants (pyx:509)
+        if (live && !ghost && aa == S && i == n && jj == m) {
+          int best = M[0];
+#pragma unroll
+          for (int q = 1; q < 9; ++q) best = imax(best, M[q]);
+          A.scores[pid] = best;
+        }
+      }
+      if (PACKED) {
         // packed record (Pack<S>): dword 0 = base, then the offsets of all values but the anchor as unsigned halfwords; a
         // piece of it leaves as soon as its last offset exists
         if (bb == 0) pk_base = M[8] - 0x8000;
@@ -425,7 +440,7 @@ __global__ void __launch_bounds__(64 * TW * PPW, 3) fill_affine_slim_kernel(cons
           } else {
             pk_acc |= e;
           }
-          pk_e[INTERIOR ? bb * 9 + q : 0] = e;
+          pk_e[PACKED ? bb * 9 + q : 0] = e;
         }
         if (do_store) {
 #pragma unroll
@@ -440,7 +455,7 @@ __global__ void __launch_bounds__(64 * TW * PPW, 3) fill_affine_slim_kernel(cons
                 const int d = 4 * c + x;
                 const int lo = d < NDWc ? PK_::val(2 * d) : 0, hi = d < NDWc ? PK_::val(2 * d + 1) : 0;
                 dw[x] = d == 0 ? pk_base
-                               : (d < NDWc ? (int)__builtin_amdgcn_perm((unsigned)pk_e[INTERIOR ? hi : 0], (unsigned)pk_e[INTERIOR ? lo : 0], 0x05040100u) : 0);
+                               : (d < NDWc ? (int)__builtin_amdgcn_perm((unsigned)pk_e[PACKED ? hi : 0], (unsigned)pk_e[PACKED ? lo : 0], 0x05040100u) : 0);
               }
               if (c < PK_::NCH) {
                 v4i v;
@@ -461,18 +476,22 @@ __global__ void __launch_bounds__(64 * TW * PPW, 3) fill_affine_slim_kernel(cons
           for (int c = 0; c < NCH4; ++c) {
             if (4 * c + 3 >= bb * 9 && 4 * c + 3 < (bb + 1) * 9) {  // chunk c completes with this point
               v4i v;
-              v.x = outv[INTERIOR ? 0 : 4 * c]; v.y = outv[INTERIOR ? 0 : 4 * c + 1];
-              v.z = outv[INTERIOR ? 0 : 4 * c + 2]; v.w = outv[INTERIOR ? 0 : 4 * c + 3];
+              v.x = outv[PACKED ? 0 : 4 * c]; v.y = outv[PACKED ? 0 : 4 * c + 1];
+              v.z = outv[PACKED ? 0 : 4 * c + 2]; v.w = outv[PACKED ? 0 : 4 * c + 3];
               *reinterpret_cast<v4i*>(dst + c * R_::CH + slot_ * 4) = v;
             }
           }
+          if (LEAN && bb == W - 1) {
+#pragma unroll
+            for (int t = 0; t < TAIL; ++t) dst[NCH4 * R_::CH + slot_ * TAIL + t] = outv[PACKED ? 0 : 4 * NCH4 + t];
+          }
         }
-        if (bb == W - 1) {  // the tail is stored by ALL 64 lanes (Rec::TAILSLOTS)
+        if (!LEAN && bb == W - 1) {  // the tail is stored by ALL 64 lanes (Rec::TAILSLOTS)
           const bool wave_stores = __builtin_amdgcn_ballot_w64(tile_act && !ghost) != 0 && (TW == 1 || rec <= rec_last);
           if (wave_stores) {
             const int tslot = (live && !ghost) ? L - W : R_::SL + (L < W ? L : W + (L - R * W));
 #pragma unroll
-            for (int t = 0; t < TAIL; ++t) dst[NCH4 * R_::CH + tslot * TAIL + t] = outv[INTERIOR ? 0 : 4 * NCH4 + t];
+            for (int t = 0; t < TAIL; ++t) dst[NCH4 * R_::CH + tslot * TAIL + t] = outv[PACKED ? 0 : 4 * NCH4 + t];
           }
         }
       }
@@ -582,7 +601,7 @@ __global__ void __launch_bounds__(64 * TW * PPW, 3) fill_affine_slim_kernel(cons
       ++g;
     }
   }
-  if (__builtin_amdgcn_ballot_w64(live && !ghost && (unsigned)pk_all > 0xffffu) != 0 && L == 0) atomicOr(A.errflag, 2);
+  if (!LEAN && __builtin_amdgcn_ballot_w64(live && !ghost && (unsigned)pk_all > 0xffffu) != 0 && L == 0) atomicOr(A.errflag, 2);
   if (TW > 1) {  // everything this wave wrote is acknowledged: release the partner for good
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (L == 0) prog_lds[w] = 0x7fffffff;

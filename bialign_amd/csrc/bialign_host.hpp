@@ -179,14 +179,14 @@ namespace bialign {
 // One launch shape: TW waves per workgroup, GW workgroups per pair (GW > 1 = cross-CU team).
 struct TeamShape {
   int tw = 1, gw = 1;
-  bool slim = false;  // the three-waves-per-SIMD kernel (fill_affine_slim_kernel), workgroups of tw = 1, 2, 3, 6 or 12 waves
+  bool slim = false;  // the three-waves-per-SIMD kernel (fill_affine_slim_kernel), teams of tw = 2, 3, 6 or 12 waves
   int waves() const { return tw * gw; }
 };
 // fill_affine_slim_kernel exists for this batch: affine, max_shift 1, LOOKUP scores, beta <= 0, packed records, full storage
 inline bool slim_available(const bialign_batch* b) {
   const char* sw = getenv("BIALIGN_SLIM");  // "0": tests / A-B, the two-wave kernels only
   const bool off = sw && atoi(sw) == 0;
-  return !off && b->affine && b->S == 1 && !b->dense && !b->lean && !b->wide && b->prm.gap_opening_cost <= 0 && b->pack_now();
+  return !off && b->affine && b->S == 1 && !b->dense && !b->wide && b->prm.gap_opening_cost <= 0 && (b->lean || b->pack_now());
 }
 
 // xcu_resident: one-wave workgroups of the cross-CU kernel the device holds at once (0: no such kernel);
@@ -230,7 +230,7 @@ int launch_fill_affine_t(bialign_batch* b, const DeviceBatch& v, int first, int 
   return BIALIGN_OK;
 }
 
-template <int S, int TW>
+template <int S, int TW, bool LEAN>
 int launch_fill_affine_slim_t(bialign_batch* b, const DeviceBatch& v, int first, int count) {
   constexpr int PPW = 12 / TW;  // pairs per twelve-wave workgroup
   DeviceBatch w = v;
@@ -238,9 +238,9 @@ int launch_fill_affine_slim_t(bialign_batch* b, const DeviceBatch& v, int first,
   w.team = 1;
   w.launch_pairs = count;
   w.slim_code_bytes = (int32_t)b->lds_slim_codes;
-  b->packed_layers = true;
-  b->used_pack = true;
-  auto kern = fill_affine_slim_kernel<S, TW, PPW>;
+  b->packed_layers = !LEAN;
+  if (!LEAN) b->used_pack = true;
+  auto kern = fill_affine_slim_kernel<S, TW, PPW, LEAN>;
   const size_t lds = b->lds_slim(TW);
   if (lds > 64 * 1024)
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -249,15 +249,14 @@ int launch_fill_affine_slim_t(bialign_batch* b, const DeviceBatch& v, int first,
   return BIALIGN_OK;
 }
 
-template <int S>
+template <int S, bool LEAN>
 int launch_fill_affine_slim(bialign_batch* b, const DeviceBatch& v, int first, int count, int tw) {
   if constexpr (S == 1) {
     switch (tw) {
-      case 1: return launch_fill_affine_slim_t<S, 1>(b, v, first, count);
-      case 2: return launch_fill_affine_slim_t<S, 2>(b, v, first, count);
-      case 3: return launch_fill_affine_slim_t<S, 3>(b, v, first, count);
-      case 6: return launch_fill_affine_slim_t<S, 6>(b, v, first, count);
-      case 12: return launch_fill_affine_slim_t<S, 12>(b, v, first, count);
+      case 2: return launch_fill_affine_slim_t<S, 2, LEAN>(b, v, first, count);
+      case 3: return launch_fill_affine_slim_t<S, 3, LEAN>(b, v, first, count);
+      case 6: return launch_fill_affine_slim_t<S, 6, LEAN>(b, v, first, count);
+      case 12: return launch_fill_affine_slim_t<S, 12, LEAN>(b, v, first, count);
     }
   }
   return fail(BIALIGN_E_UNSUPPORTED, "no three-waves-per-SIMD sweep for max_shift %d, team %d", S, tw);
@@ -301,9 +300,7 @@ int launch_fill_affine_l(bialign_batch* b, const DeviceBatch& v, int first, int 
                                 : team_shape(b, first, count, xcu_ok ? xcu_resident_blocks<S, LEAN>(b) : 0,
                                              xcu_ok ? xcu_resident_blocks<S, LEAN, 8>(b) : 0);
   b->last_team = ts.waves() * (ts.gw > 1 ? -1 : 1);
-  if constexpr (!LEAN) {
-    if (ts.slim) return launch_fill_affine_slim<S>(b, v, first, count, ts.tw);
-  }
+  if (ts.slim) return launch_fill_affine_slim<S, LEAN>(b, v, first, count, ts.tw);
   if (b->dense) {  // dense-mu2 kernels: one-wave cross-CU teams, in-workgroup teams of 4 and 2, one wave
     if constexpr (S >= 1 && S <= BIALIGN_MAX_SHIFT_PACKED && !LEAN) {
       if (b->pack_now()) {

@@ -79,7 +79,7 @@ def test_forced_on_short_pairs(n, m, s, seed, monkeypatch):
 
 
 @pytest.mark.parametrize("team,n,m,s", [("2", 300, 320, 1), ("4", 170, 400, 1), ("8", 330, 650, 1), ("x3", 130, 300, 1),
-                                        ("1", 90, 200, 1), ("3", 300, 320, 1), ("6", 330, 650, 1), ("12", 500, 1000, 1),  # (1, 2, 3, 6, 12 at s=1: the three-waves-per-SIMD kernel)
+                                        ("1", 90, 200, 1), ("3", 300, 320, 1), ("6", 330, 650, 1), ("12", 500, 1000, 1),  # (2, 3, 6, 12 at s=1: the three-waves-per-SIMD kernel)
                                         ("x8", 330, 650, 1), ("4", 100, 300, 2), ("8", 200, 470, 2), ("x7", 200, 400, 2),
                                         ("h2", 360, 810, 2), ("4", 80, 300, 3), ("x4", 90, 400, 3)])
 def test_team_shapes(team, n, m, s, monkeypatch):

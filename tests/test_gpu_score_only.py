@@ -53,6 +53,32 @@ def test_multi_strip_and_team_shapes(n, m, s, ov, team, monkeypatch):
         assert tl["waves_per_pair"] == (8 * int(team[1:]) if team[0] == "h" else int(team.lstrip("x")))
 
 
+@pytest.mark.parametrize("team,n,m", [("2", 300, 310), ("3", 300, 320), ("6", 330, 650), ("12", 500, 1000)])
+def test_three_waves_per_simd_sweep_score_only_and_lean_trace(team, n, m, monkeypatch):
+    """s=1, teams of 2, 3, 6, 12: fill_affine_slim_kernel in its LEAN form (score-only batches and the sweep of the
+    memory-lean traceback) against the oracle -- scores, and the traces the strip re-sweeps recover from its rows."""
+    from oracle import oracle
+    from bialign_amd.batch import make_batch
+    from bialign_amd.engine import trace_codes_to_columns
+    monkeypatch.setenv("BIALIGN_TEAM", team)
+    pairs = [synth.protein_pair(880 + t, n - 7 * t, m + 5 * t) for t in range(3)]
+    params = dict(synth.PROTEIN_PARAMS)
+    refs = [oracle.solve(*p, params) for p in pairs]
+    b = make_batch(pairs, params, score_only=True)
+    b.run()
+    assert b.timing()["waves_per_pair"] == int(team)
+    assert [int(x) for x in b.scores()] == [r["score"] for r in refs]
+    b.close()
+    b = make_batch(pairs, params, lean_trace=True)
+    b.run()
+    assert b.timing()["waves_per_pair"] == int(team)
+    traces, ok = b.traces()
+    assert [int(x) for x in b.scores()] == [r["score"] for r in refs]
+    for t, r in enumerate(refs):
+        assert trace_codes_to_columns(traces[t]) == oracle.trace_to_lists(r["trace"]) and bool(ok[t]) == r["complete"]
+    b.close()
+
+
 def test_dense_mu2_score_only():
     rng = np.random.default_rng(5)
     shapes = [(130, 75), (75, 130), (40, 50), (300, 280)]
