@@ -103,6 +103,9 @@ TeamShape team_shape(const bialign_batch* b, int first, int count, int xcu_resid
     int64_t best_old = 0;  // what the two-wave kernels' in-workgroup teams keep running at best
     for (int c = 1; c <= tw; c *= 2) best_old = std::max(best_old, concurrent(c));
     if (pick && !e && conc_slim(pick) < best_old) pick = 0;  // (e.g. 256 pairs whose period admits teams of 6: 1536 waves against 2048)
+    // its twelve-wave workgroups must cover the device: a third wave on a SIMD adds a few percent, an idle CU costs all of
+    // it (117 pairs x len 1024: teams of 12 on 117 CUs 11.0 ms, cross-CU teams of 13 one-wave workgroups on all CUs 9.7)
+    if (pick && !e && ((int64_t)count * pick + 11) / 12 * 10 < (int64_t)b->eng->num_cu * 9) pick = 0;
     if (pick) {
       // (a handful of long pairs still go to cross-CU teams of the two-wave kernel below when that spreads them wider)
       const int64_t run_s = conc_slim(pick);
