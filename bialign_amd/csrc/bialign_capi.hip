@@ -488,8 +488,10 @@ int bialign_batch_create(bialign_engine* eng, const bialign_params* prm, const b
   b->lean_trace = (prm->flags & BIALIGN_BATCH_LEAN_TRACE) != 0;
   b->lean = b->lean_trace || (prm->flags & BIALIGN_BATCH_SCORE_ONLY) != 0;
   b->wide = prm->max_shift > BIALIGN_MAX_SHIFT_TILED;  // bialign_wide.hpp: anti-diagonal path, all layers in HBM
-  if (b->wide && b->lean)
-    return fail(BIALIGN_E_UNSUPPORTED, "reduced layer storage (SCORE_ONLY / LEAN_TRACE) exists for max_shift <= %d only",
+  // wide bands: score-only batches of the affine recurrence keep just the ring of derived values (bialign_wide.hpp);
+  // the memory-lean traceback and the one-layer recurrence's score-only form exist for the tiled sweeps only
+  if (b->wide && b->lean && (b->lean_trace || !b->affine))
+    return fail(BIALIGN_E_UNSUPPORTED, "LEAN_TRACE, and SCORE_ONLY of the non-affine recurrence, exist for max_shift <= %d only",
                 BIALIGN_MAX_SHIFT_TILED);
   if (b->dense && !pr->mu2_off) return fail(BIALIGN_E_INVALID, "mu2_dense given without mu2_off");
   if (!b->dense && (!pr->cls_a || !pr->cls_b)) return fail(BIALIGN_E_INVALID, "cls_a / cls_b are NULL (LOOKUP form)");
@@ -585,8 +587,8 @@ int bialign_batch_create(bialign_engine* eng, const bialign_params* prm, const b
   auto size_pairs = [&]() {
     for (int p = 0; p < pr->npairs; ++p) {
       PairDesc& d = b->pairs[p];
-      if (b->wide) {  // reference-order layers, every band slot of every (i, j)
-        pair_dwords[p] = wide_pair_dwords(d.n, d.m, S, b->NL);
+      if (b->wide) {  // reference-order layers, every band slot of every (i, j); none at all for a score-only batch
+        pair_dwords[p] = b->lean ? 16 : wide_pair_dwords(d.n, d.m, S, b->NL);
         continue;
       }
       int slp = (64 / W - 1) * W;  // Rec<S,NL>::SLP

@@ -131,6 +131,8 @@ struct bialign_batch {
   std::vector<int64_t> full_dwords;    // per pair: dwords of its full-record form (for the fallback's re-plan)
   DevBuf<uint8_t> d_seq_a, d_cls_a, d_seq_b, d_cls_b, d_trace;
   DevBuf<int32_t> d_mu2;  // dense-mu2 mode: all pairs' n x m tables
+  DevBuf<int32_t> d_wide_ring;  // wide-band affine sweep: derived values of the last levels (bialign_wide.hpp)
+  DevBuf<int64_t> d_wide_off;   // ... per pair of a launch: offset of its ring
   bool dense = false;
   bool wide = false;        // max_shift above the tiled kernels: anti-diagonal path (bialign_wide.hpp), reference-order layers
   bool lean = false;        // LEAN records: the sweep keeps only the strip-bottom rows

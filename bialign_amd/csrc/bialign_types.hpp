@@ -53,6 +53,9 @@ struct DeviceBatch {
   int32_t wide_s;       // wide-band path (max_shift beyond the tiled kernels): the band half-width
   int32_t prio_mode;    // 1 = rotate wave priorities by workgroup age (fill_affine_kernel); BIALIGN_PRIO=0 switches it off
   int32_t spin_limit;   // team hand-off: polls of the partner's progress word before a wave gives up (error flag)
+  int32_t* wide_ring;            // wide-band affine sweep: derived values of the last WIDE_RING levels, all pairs of the launch
+  const int64_t* wide_ring_off;  // ... [pairs in launch]: dword offset of a pair's ring
+  int32_t wide_score_only;       // ... 1: no layers are stored, the last level's point writes the score
   int32_t launch_pairs;     // fill_affine_slim_kernel: pairs of this launch (a workgroup holds several)
   int32_t slim_code_bytes;  // fill_affine_slim_kernel: LDS bytes of one pair's sequence and class codes
 };

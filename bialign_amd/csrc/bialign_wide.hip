@@ -30,6 +30,21 @@ int launch_fill_wide(bialign_batch* b, const DeviceBatch& v, int first, int coun
     if (const char* e = getenv("BIALIGN_WIDE_PARTS")) parts = std::max(1, std::min(atoi(e), parts));  // tests
   }
   w.team = parts;
+  if (b->affine) {  // ring of derived values (bialign_wide.hpp): WIDE_RING levels per pair of this launch
+    std::vector<int64_t> off(count);
+    int64_t total = 0;
+    for (int t = 0; t < count; ++t) {
+      off[t] = total;
+      total += WIDE_RING * wide_ring_level_dwords(b->pairs[b->order[first + t]].n, b->S);
+    }
+    if (b->d_wide_ring.n < (size_t)total) HIP_TRY(b->d_wide_ring.alloc((size_t)total));
+    if (b->d_wide_off.n < (size_t)count) HIP_TRY(b->d_wide_off.alloc((size_t)count));
+    HIP_TRY(hipMemcpyAsync(b->d_wide_off.p, off.data(), sizeof(int64_t) * count, hipMemcpyHostToDevice, b->eng->stream));
+    HIP_TRY(hipStreamSynchronize(b->eng->stream));  // (`off` goes out of scope; a launch per chunk, not per step of a sweep)
+    w.wide_ring = b->d_wide_ring.p;
+    w.wide_ring_off = b->d_wide_off.p;
+    w.wide_score_only = b->lean ? 1 : 0;
+  }
   w.spin_limit = b->xcu_spin_limit;
   b->last_team = parts * (WIDE_THREADS / 64) * (parts > 1 ? -1 : 1);
   if (b->d_prog.n < (size_t)count * PROG_WORDS) HIP_TRY(b->d_prog.alloc((size_t)count * PROG_WORDS));

@@ -16,13 +16,16 @@
 
 namespace bialign {
 
-// dword index of state st of lattice point (i, j, aa, bb) in a wide-band pair's region
+// dword index of state st of lattice point (i, j, aa, bb) in a wide-band pair's region.  The nine states of the affine
+// recurrence sit in a 12-dword cell: 16-byte aligned, so a point's layers leave as three dwordx4 stores (an
+// unaligned dwordx4 store is not something to rely on: the first version with 9-dword cells read back garbage).
+__host__ __device__ inline int wide_pitch(int NL) { return NL == 9 ? 12 : NL; }
 __host__ __device__ inline int64_t wide_dword(int m, int W, int NL, int i, int j, int aa, int bb, int st) {
-  return ((((int64_t)i * (m + 1) + j) * W + aa) * W + bb) * NL + st;
+  return ((((int64_t)i * (m + 1) + j) * W + aa) * W + bb) * wide_pitch(NL) + st;
 }
 __host__ __device__ inline int64_t wide_pair_dwords(int n, int m, int S, int NL) {
   const int64_t W = 2 * S + 1;
-  return (int64_t)(n + 1) * (m + 1) * W * W * NL;
+  return (int64_t)(n + 1) * (m + 1) * W * W * wide_pitch(NL);
 }
 
 struct WideCtx {
@@ -105,10 +108,33 @@ __device__ __forceinline__ void wide_level_sync(const DeviceBatch& A, int32_t* c
 }
 
 // ---------------------------------------------------------------------------
-// Affine fill (pyx:474-509), literal: per target state the fifteen cases of pyx:275-296.  A point's fifteen
-// predecessor cells (one per nonzero offset in {0,1}^4) are loaded up front, nine states each: one memory
-// round trip per point.
+// Affine fill (pyx:474-509) with the tiled sweep's algebra (bialign_kernels.hpp: bit-exact regrouping of the fifteen
+// cases per state).  Beside its nine layer values a point writes 27 DERIVED values
+//   G[U][V] = f_U(H2[.][V]),  H2[U][V] = f_V(M[(U,.)]),  H3[U][V] = f_U(M[(.,V)]),   f_T(v) = max_h(open(h,T) + v[h])
+// into a ring of the last WIDE_RING levels (a predecessor lowers D by 1..4), and a target state (U,V) then needs ONE
+// value from each of three predecessor cells -- G[U][V](q-(U,V)), H2[U][V](q-(0,0,V)), H3[U][V](q-(U,0,0)) -- instead
+// of nine, three and three layer values: 27 four-byte loads per point instead of 135 (round 2), and vector stores
+// (16 bytes, write-through) instead of nine scalar ones.  The ring is indexed [D mod WIDE_RING][i][a][b/2] (within a
+// level b has one parity); a slot is 28 dwords (16-byte aligned): G at 3U+V, H2 at 9+3V+U (fixed V contiguous), H3 at 18+3U+V.
+// With A.wide_score_only the layers themselves are not stored at all: the last level's one point writes the score.
 // ---------------------------------------------------------------------------
+constexpr int WIDE_RING = 5, WIDE_SLOT = 28;
+__host__ __device__ inline int64_t wide_ring_level_dwords(int n, int S) {
+  const int64_t W = 2 * S + 1;
+  return (int64_t)(n + 1) * W * ((W + 1) / 2) * WIDE_SLOT;
+}
+__device__ __forceinline__ void wide_store4(int32_t* p, int a, int b, int c, int d) {
+  v4i v;
+  v.x = a; v.y = b; v.z = c; v.w = d;
+  // write-through; p is 16-byte aligned.  s_nop 1: a store of more than 8 bytes must not be followed at once by a write of
+  // its data registers, and the hazard recogniser does not look inside asm (as in store_chunk of the tiled sweep)
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+}
+// f_T for target half Y, X, M over the values of source halves (y, x, m); exact for any sign of beta
+__device__ __forceinline__ int wfY(int y, int x, int m, int beta) { return max(y, beta + max(x, m)); }
+__device__ __forceinline__ int wfX(int y, int x, int m, int beta) { return max(x, beta + max(y, m)); }
+__device__ __forceinline__ int wfM(int y, int x, int m) { return max(max(y, x), m); }
+
 template <int UNUSED = 0>  // (a template so that only bialign_wide.hip instantiates it)
 __global__ void __launch_bounds__(WIDE_THREADS) fill_wide_affine_kernel(const DeviceBatch A, int S) {
   const int parts = A.team, slot = blockIdx.x / parts, part = blockIdx.x - slot * parts;
@@ -121,64 +147,103 @@ __global__ void __launch_bounds__(WIDE_THREADS) fill_wide_affine_kernel(const De
   c.sa = A.seq_a + pd.seq_a; c.ca = A.cls_a + pd.seq_a; c.sb = A.seq_b + pd.seq_b; c.cb = A.cls_b + pd.seq_b;
   c.mu2tab = A.mu2_dense ? A.mu2_dense + pd.mu2_off : nullptr;
   c.lay = A.layers + pd.layer_off;
-  const int n = c.n, m = c.m, W = c.W;
+  const int n = c.n, m = c.m, W = c.W, HW = (W + 1) / 2;
   const int beta = c.beta, gamma = c.gamma, delta = c.delta;
   int32_t* const counter = A.prog + (int64_t)slot * PROG_WORDS;
+  int32_t* const ring = A.wide_ring + A.wide_ring_off[slot];
+  const int64_t lvl = wide_ring_level_dwords(n, S);
+  const bool keep_layers = !A.wide_score_only;
   bool failed = false;  // (thread 0: a level barrier timed out, no further waits)
 
+  // ring slot of lattice point (i, a, b) of level Dq
+  auto rslot = [&](int Dq, int i, int aa, int bb) -> int32_t* {
+    return ring + (Dq % WIDE_RING) * lvl + ((int64_t)(i * W + aa) * HW + (bb >> 1)) * WIDE_SLOT;
+  };
   for (int D = 0; D <= 2 * (n + m); ++D) {
     wide_for_level(c, D, part, parts, [&](int i, int j, int k, int l, int aa, int bb) {
-      int32_t* out = c.lay + wide_dword(m, W, 9, i, j, aa, bb, 0);
+      int M[9];
       if (D == 0) {  // pyx:483-485
 #pragma unroll
-        for (int q = 0; q < 9; ++q) wide_store(out + q, q == 8 ? 0 : NEG);
-        return;
-      }
-      // predecessor cells by offset code o0*8 + o1*4 + o2*2 + o3 (1..15); an invalid one (pyx:133-141) is not read
-      int pred[16][9];
-      bool ok[16];
-      ok[0] = false;
+        for (int q = 0; q < 9; ++q) M[q] = q == 8 ? 0 : NEG;
+      } else {
+        // the fifteen predecessor cells by offset code o0*8 + o1*4 + o2*2 + o3; an invalid one (pyx:133-141) is not read
+        bool ok[16];
+        const int32_t* src[16];
+        ok[0] = false;
+        src[0] = ring;
 #pragma unroll
-      for (int code = 1; code < 16; ++code) {
-        const int pi = i - ((code >> 3) & 1), pj = j - ((code >> 2) & 1), pk = k - ((code >> 1) & 1), pl = l - (code & 1);
-        ok[code] = c.valid(pi, pj, pk, pl);
-        const int32_t* src = ok[code] ? c.lay + wide_dword(m, W, 9, pi, pj, pk - pi + S, pl - pj + S, 0) : out;
-        wide_load9(src, pred[code]);
-      }
-      const int mu1 = c.mu1(i, j), mu2 = c.mu2(k, l);
-#pragma unroll
-      for (int hU = 0; hU < 3; ++hU) {
-#pragma unroll
-        for (int hV = 0; hV < 3; ++hV) {
-          const int u0 = hU >= 1, u1 = hU != 1, v0 = hV >= 1, v1 = hV != 1;
-          const int valU = hU == 2 ? mu1 : gamma, valV = hV == 2 ? mu2 : gamma;
-          bool any = false;
-          int best = NEG;  // pyx:299-303: no valid case -> exactly NEG
-          auto take = [&](int v) { best = any ? (v > best ? v : best) : v; any = true; };
-          const int c1 = u0 * 8 + u1 * 4 + v0 * 2 + v1;  // group 1 (pyx:275-279): offset = the target state, all nine sources
-          if (ok[c1]) {
-            const int sh = hU == hV ? 0 : ((hU == 2 || hV == 2) ? 1 : 2);
-            const int base = delta * sh + valU + valV;
-#pragma unroll
-            for (int r = 0; r < 9; ++r) {
-              const int ra = r / 3, rb = r % 3;
-              take(pred[c1][r] + base + ((hU != 2 && ra != hU) ? beta : 0) + ((hV != 2 && rb != hV) ? beta : 0));
-            }
-          }
-          const int c2 = v0 * 2 + v1;  // group 2 (pyx:284-290): offset (0,0,V), sources (U,h), h = M, X, Y
-          if (ok[c2]) {
-            const int base = delta * (v0 + v1) + valV;
-#pragma unroll
-            for (int h = 2; h >= 0; --h) take(pred[c2][3 * hU + h] + base + ((hV != 2 && h != hV) ? beta : 0));
-          }
-          const int c3 = u0 * 8 + u1 * 4;  // group 3 (pyx:291-296): offset (U,0,0), sources (h,V)
-          if (ok[c3]) {
-            const int base = delta * (u0 + u1) + valU;
-#pragma unroll
-            for (int h = 2; h >= 0; --h) take(pred[c3][3 * h + hV] + base + ((hU != 2 && h != hU) ? beta : 0));
-          }
-          wide_store(out + 3 * hU + hV, best);
+        for (int code = 1; code < 16; ++code) {
+          const int o0 = (code >> 3) & 1, o1 = (code >> 2) & 1, o2 = (code >> 1) & 1, o3 = code & 1;
+          const int pi = i - o0, pj = j - o1, pk = k - o2, pl = l - o3;
+          ok[code] = c.valid(pi, pj, pk, pl);
+          src[code] = ok[code] ? rslot(D - o0 - o1 - o2 - o3, pi, pk - pi + S, pl - pj + S) : ring;
         }
+        int g[9], h2[9], h3[9];  // [3*hU + hV]: the one value each group contributes to target state (hU, hV)
+#pragma unroll
+        for (int hU = 0; hU < 3; ++hU) {
+#pragma unroll
+          for (int hV = 0; hV < 3; ++hV) {
+            const int u0 = hU >= 1, u1 = hU != 1, v0 = hV >= 1, v1 = hV != 1;
+            const int c1 = u0 * 8 + u1 * 4 + v0 * 2 + v1, c2 = v0 * 2 + v1, c3 = u0 * 8 + u1 * 4;
+            g[3 * hU + hV] = __hip_atomic_load(src[c1] + 3 * hU + hV, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            h2[3 * hU + hV] = __hip_atomic_load(src[c2] + 9 + 3 * hV + hU, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            h3[3 * hU + hV] = __hip_atomic_load(src[c3] + 18 + 3 * hU + hV, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+        }
+        const int mu1 = c.mu1(i, j), mu2 = c.mu2(k, l);
+#pragma unroll
+        for (int hU = 0; hU < 3; ++hU) {
+#pragma unroll
+          for (int hV = 0; hV < 3; ++hV) {
+            const int u0 = hU >= 1, u1 = hU != 1, v0 = hV >= 1, v1 = hV != 1;
+            const int valU = hU == 2 ? mu1 : gamma, valV = hV == 2 ? mu2 : gamma;
+            const int c1 = u0 * 8 + u1 * 4 + v0 * 2 + v1, c2 = v0 * 2 + v1, c3 = u0 * 8 + u1 * 4;
+            const int sh = hU == hV ? 0 : ((hU == 2 || hV == 2) ? 1 : 2);
+            bool any = false;
+            int best = NEG;  // pyx:299-303: no valid case -> exactly NEG
+            auto take = [&](int v) { best = any ? (v > best ? v : best) : v; any = true; };
+            if (ok[c1]) take(g[3 * hU + hV] + delta * sh + valU + valV);        // group 1 (pyx:275-279)
+            if (ok[c2]) take(h2[3 * hU + hV] + delta * (v0 + v1) + valV);       // group 2 (pyx:284-290)
+            if (ok[c3]) take(h3[3 * hU + hV] + delta * (u0 + u1) + valU);       // group 3 (pyx:291-296)
+            M[3 * hU + hV] = best;
+          }
+        }
+      }
+      // derived values for the successors
+      int H2[3][3], H3[3][3], G[3][3];
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+        H2[u][0] = wfY(M[3 * u], M[3 * u + 1], M[3 * u + 2], beta);
+        H2[u][1] = wfX(M[3 * u], M[3 * u + 1], M[3 * u + 2], beta);
+        H2[u][2] = wfM(M[3 * u], M[3 * u + 1], M[3 * u + 2]);
+      }
+#pragma unroll
+      for (int v = 0; v < 3; ++v) {
+        H3[0][v] = wfY(M[v], M[3 + v], M[6 + v], beta);
+        H3[1][v] = wfX(M[v], M[3 + v], M[6 + v], beta);
+        H3[2][v] = wfM(M[v], M[3 + v], M[6 + v]);
+        G[0][v] = wfY(H2[0][v], H2[1][v], H2[2][v], beta);
+        G[1][v] = wfX(H2[0][v], H2[1][v], H2[2][v], beta);
+        G[2][v] = wfM(H2[0][v], H2[1][v], H2[2][v]);
+      }
+      int32_t* r = rslot(D, i, aa, bb);
+      wide_store4(r + 0, G[0][0], G[0][1], G[0][2], G[1][0]);
+      wide_store4(r + 4, G[1][1], G[1][2], G[2][0], G[2][1]);
+      wide_store4(r + 8, G[2][2], H2[0][0], H2[1][0], H2[2][0]);       // H2 at 9 + 3V + U
+      wide_store4(r + 12, H2[0][1], H2[1][1], H2[2][1], H2[0][2]);
+      wide_store4(r + 16, H2[1][2], H2[2][2], H3[0][0], H3[0][1]);     // H3 at 18 + 3U + V
+      wide_store4(r + 20, H3[0][2], H3[1][0], H3[1][1], H3[1][2]);
+      wide_store4(r + 24, H3[2][0], H3[2][1], H3[2][2], 0);
+      if (keep_layers) {
+        int32_t* out = c.lay + wide_dword(m, W, 9, i, j, aa, bb, 0);
+        wide_store4(out, M[0], M[1], M[2], M[3]);
+        wide_store4(out + 4, M[4], M[5], M[6], M[7]);
+        wide_store4(out + 8, M[8], 0, 0, 0);
+      } else if (D == 2 * (n + m)) {  // score-only: the end cell (n,m,n,m) is all the host wants (pyx:509)
+        int best = M[0];
+#pragma unroll
+        for (int q = 1; q < 9; ++q) best = max(best, M[q]);
+        A.scores[pid] = best;
       }
     });
     wide_level_sync(A, counter, D, parts, failed);
@@ -250,7 +315,7 @@ __global__ void dump_wide_kernel(const DeviceBatch A, int S, int pid, int32_t* o
     const int j = (t / (W * W)) % (m + 1), i = t / ((int64_t)W * W * (m + 1));
     const int k = i + aa - S, l = j + bb - S;
     const bool ok = k >= 0 && k <= n && l >= 0 && l <= m;
-    for (int q = 0; q < NL; ++q) out[q * cells + t] = ok ? A.layers[pd.layer_off + t * NL + q] : 0;
+    for (int q = 0; q < NL; ++q) out[q * cells + t] = ok ? A.layers[pd.layer_off + t * wide_pitch(NL) + q] : 0;
   }
 }
 

@@ -63,13 +63,16 @@ extern "C" {
 /* bialign_params.flags.  SCORE_ONLY: the batch will only ever be asked for scores (optimize()
  * without a later traceback(), e.g. all-against-all scoring): the sweep keeps just the rows the
  * next strip needs instead of all layers -- 1/20 of the HBM footprint and traffic at max_shift 1 --
- * and bialign_batch_get_traces / bialign_batch_dump_layers fail with BIALIGN_E_INVALID. */
+ * and bialign_batch_get_traces / bialign_batch_dump_layers fail with BIALIGN_E_INVALID.  Beyond
+ * BIALIGN_MAX_SHIFT_TILED: the affine recurrence only (no layers at all are stored there, just a ring of the
+ * last five anti-diagonal levels' derived values); BIALIGN_E_UNSUPPORTED for the non-affine one. */
 #define BIALIGN_BATCH_SCORE_ONLY 1u
 /* LEAN_TRACE: full results (scores and traces) from the same reduced storage: after the lean sweep
  * the traceback re-sweeps strips of lattice rows into a per-pair scratch area -- as many at a time as
  * keep the device busy and the HBM budget allows, at most a quarter of the pair's full layers -- and
  * walks through them.  A twelfth to a third of the HBM footprint of the default mode (hbm_budget_bytes
- * decides) for ~1.1-1.3x the time: for pairs whose layers would not fit otherwise. */
+ * decides) for ~1.1-1.3x the time: for pairs whose layers would not fit otherwise.  max_shift <=
+ * BIALIGN_MAX_SHIFT_TILED only (BIALIGN_E_UNSUPPORTED beyond). */
 #define BIALIGN_BATCH_LEAN_TRACE 2u
 
 typedef struct bialign_engine bialign_engine; /* one per (process, device) */

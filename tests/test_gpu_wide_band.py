@@ -46,7 +46,7 @@ def test_ragged_chunked_batch_vs_oracle(dense):
     pairs = [synth.protein_pair(3100 + t, n, m) for t, (n, m) in enumerate(shapes)]
     tabs = [rng.integers(-500, 1500, size=(n, m)).astype(np.int32) for n, m in shapes] if dense else None
     params = dict(synth.PROTEIN_PARAMS, max_shift=7)
-    for budget in (0, 12 << 20):
+    for budget in (0, 16 << 20):   # (the largest pair's layers are 14.8 MB: 12-dword cells since round 3)
         b = make_batch(pairs, params, hbm_budget_bytes=budget, mu2_dense=tabs)
         if budget:
             assert b.info["nchunks"] > 1
@@ -105,14 +105,39 @@ def test_lost_co_residency_is_recovered(monkeypatch):
                 (oracle.trace_to_lists(ref["trace"]) if p["gap_opening_cost"] else [tuple(c) for c in oracle.trace_to_lists(ref["trace"])])
 
 
-def test_reduced_storage_is_refused_beyond_the_tiled_band():
+def test_reduced_storage_beyond_the_tiled_band():
+    """Round 3: score-only batches of the affine recurrence exist for wide bands too (the ring of derived values is
+    all the sweep keeps); the memory-lean traceback and the one-layer recurrence's score-only form are still refused."""
     from bialign_amd import _lib
     from bialign_amd.batch import make_batch
     pair = synth.protein_pair(3200, 20, 20)
-    for kw in (dict(score_only=True), dict(lean_trace=True)):
+    for params, kw in ((dict(synth.PROTEIN_PARAMS, max_shift=6), dict(lean_trace=True)),
+                       (dict(synth.PROTEIN_PARAMS, max_shift=6, **LIN), dict(score_only=True))):
         with pytest.raises(_lib.BialignError) as e:
-            make_batch([pair], dict(synth.PROTEIN_PARAMS, max_shift=6), **kw)
+            make_batch([pair], params, **kw)
         assert e.value.code == _lib.E_UNSUPPORTED
+
+
+@pytest.mark.parametrize("s,parts", [(6, None), (8, "3"), (12, "1"), (7, "64")])
+def test_score_only_wide_band_vs_oracle(s, parts, monkeypatch):
+    from oracle import oracle
+    from bialign_amd import _lib
+    from bialign_amd.batch import make_batch
+    if parts:
+        monkeypatch.setenv("BIALIGN_WIDE_PARTS", parts)
+    pairs = [synth.protein_pair(3300 + t, 30 + 11 * t, 55 - 9 * t) for t in range(4)] + [synth.protein_pair(3310, 3, 40)]
+    for params in (dict(synth.PROTEIN_PARAMS, max_shift=s), dict(synth.PROTEIN_PARAMS, max_shift=s, gap_opening_cost=70)):
+        b = make_batch(pairs, params, score_only=True)
+        full = make_batch(pairs, params)
+        assert b.info["hbm_layer_bytes"] * 100 < full.info["hbm_layer_bytes"]
+        b.run()
+        full.run()
+        np.testing.assert_array_equal(b.scores(), full.scores())
+        assert [int(x) for x in b.scores()] == [oracle.solve(*p, params, want_trace=False)["score"] for p in pairs]
+        with pytest.raises(_lib.BialignError):
+            b.traces()
+        b.close()
+        full.close()
 
 
 def test_cli_takes_max_shift_8():
