@@ -191,12 +191,13 @@ def test_batch_cli_equals_single_pair_cli(tmp_path, capsys):
 
 
 def test_cli_reports_engine_refusals_like_input_errors(tmp_path, capsys):
-    """--score_only beyond the tiled band and scores outside the int32 window: "ERROR: ..." and exit, no traceback."""
+    """--score_only of the non-affine recurrence beyond the tiled band and scores outside the int32 window: "ERROR: ..."
+    and exit, no traceback."""
     from bialign_amd import batch_cli, cli
     tsv = tmp_path / "pairs.tsv"
     tsv.write_text("a\tARND\tHHEE\tb\tARNE\tHHEC\n")
     with pytest.raises(SystemExit) as e:
-        batch_cli.main([str(tsv), "--type", "Protein", "--gap_opening_cost", "-150", "--max_shift", "8", "--score_only"])
+        batch_cli.main([str(tsv), "--type", "Protein", "--gap_opening_cost", "0", "--max_shift", "8", "--score_only"])
     assert e.value.code == -1 and capsys.readouterr().out.startswith("ERROR: ")
     with pytest.raises(SystemExit) as e:
         cli.main(["ARND", "ARNE", "--strA", "HHEE", "--strB", "HHEC", "--type", "Protein", "--gap_opening_cost", "-150",
@@ -211,8 +212,8 @@ def test_c_abi_error_paths():
     from bialign_amd.batch import make_batch
     from bialign_amd.engine import Engine
     pairs = [synth.protein_pair(1, 12, 9)]
-    with pytest.raises(_lib.BialignError) as e:   # wide bands run (test_gpu_wide_band.py), but not in reduced storage
-        make_batch(pairs, dict(synth.PROTEIN_PARAMS, max_shift=6), score_only=True)
+    with pytest.raises(_lib.BialignError) as e:   # wide bands run (test_gpu_wide_band.py), score-only too, but not the lean traceback
+        make_batch(pairs, dict(synth.PROTEIN_PARAMS, max_shift=6), lean_trace=True)
     assert e.value.code == _lib.E_UNSUPPORTED and "max_shift" in e.value.message
     with pytest.raises(_lib.BialignError) as e:
         make_batch(pairs, dict(synth.PROTEIN_PARAMS, max_shift=-1))
