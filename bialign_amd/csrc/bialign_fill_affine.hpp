@@ -115,6 +115,11 @@ __global__ void __launch_bounds__(64 * TW) BIALIGN_WPE_ATTR fill_affine_kernel(c
   const int il = L / W, aa = L - il * W;
   const bool live = L < R * W;
   const bool ghost = (il == 0);
+  // the lanes that compute in interior steps, as a laundered register: the compiler then keeps the predicate as a mask
+  // instead of re-deriving it from the lane number at every point of every step
+  int computing_v = ghost ? 0 : 1;
+  asm volatile("" : "+v"(computing_v));
+  const bool computing = computing_v != 0;
   const int beta = A.beta, gamma = A.gamma, delta = A.delta;
   const int k1 = A.k1, k2 = A.k2;
   const int gD = gamma + delta, gg = 2 * gamma, ggdd = 2 * gamma + 2 * delta, dd = 2 * delta;
@@ -596,7 +601,7 @@ __global__ void __launch_bounds__(64 * TW) BIALIGN_WPE_ATTR fill_affine_kernel(c
         // execution mask (no per-value select)
 #pragma unroll
         for (int q = 0; q < 9; ++q) M[q] = ghostM[bb * 9 + q];
-        if (!ghost) {
+        if (computing) {
           int Tv[9];
           cases(Tv);
 #pragma unroll

@@ -54,7 +54,19 @@ __global__ void __launch_bounds__(64 * TW * PPW, 3) fill_affine_slim_kernel(cons
   const int il = L / W, aa = L - il * W;
   const bool live = L < R * W;
   const bool ghost = (il == 0);
-  const bool ringfed = ghost || !live;   // lanes whose layers come out of LDS: the ghost row, and lane 63 (sentinels)
+  // lanes whose layers come out of LDS: the ghost row, and lane 63 (sentinels).  Kept as a laundered register: as a
+  // predicate the compiler can see through (L < W || L >= R W) it is re-derived at every point of every step -- three
+  // compares and two nested exec regions where one compare and one region do
+  int ringfed_v = (ghost || !live) ? 1 : 0;
+  asm volatile("" : "+v"(ringfed_v));
+  const bool ringfed = ringfed_v != 0;
+  int storing_v;  // lanes that own storage slots: the real rows (LEAN: the bottom one) and, in full records, the pad lanes
+  {
+    const int pad_idx0 = L < W ? L : (L >= R * W ? W + (L - R * W) : 64);
+    storing_v = ((live && (LEAN ? il == R - 1 : !ghost)) || (!LEAN && pad_idx0 < R_::SLP - R_::SL)) ? 1 : 0;
+  }
+  asm volatile("" : "+v"(storing_v));
+  const bool storing = storing_v != 0;
   const int beta = A.beta, gamma = A.gamma, delta = A.delta;
   const int k1 = A.k1, k2 = A.k2;
   const int gD = gamma + delta, gg = 2 * gamma, ggdd = 2 * gamma + 2 * delta, dd = 2 * delta;
@@ -301,8 +313,10 @@ __global__ void __launch_bounds__(64 * TW * PPW, 3) fill_affine_slim_kernel(cons
     const int pad_idx = L < W ? L : (L >= R * W ? W + (L - R * W) : 64);
     const bool pad_lane = pad_idx < R_::SLP - R_::SL;
     constexpr bool PACKED = INTERIOR && !LEAN;  // this step writes a packed record
-    const bool do_store = ((live && (LEAN ? il == R - 1 : !ghost)) || (!LEAN && pad_lane)) &&
-                          (INTERIOR || __builtin_amdgcn_ballot_w64(tile_act && !ghost) != 0) && (TW == 1 || rec <= rec_last);
+    // (in an interior step every lane's record exists -- rec <= rec_last -- so who stores is a lane constant)
+    const bool do_store = INTERIOR ? storing
+                                   : (((live && (LEAN ? il == R - 1 : !ghost)) || (!LEAN && pad_lane)) &&
+                                      __builtin_amdgcn_ballot_w64(tile_act && !ghost) != 0 && (TW == 1 || rec <= rec_last));
     const int slot_ = LEAN ? aa : (pad_lane ? R_::SL + pad_idx : L - W);
     if (INTERIOR) vm_younger += PACKED ? PK_::NPC : GF::STORES_PER_STEP;  // (an interior step always stores)
     else if (__builtin_amdgcn_ballot_w64(do_store) != 0) vm_younger += GF::STORES_PER_STEP;
