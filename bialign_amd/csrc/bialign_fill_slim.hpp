@@ -112,6 +112,8 @@ __global__ void __launch_bounds__(64 * TW * PPW, 3) fill_affine_slim_kernel(cons
   // the band -- lane 63, whose derived values are all sentinels.  Ghost lanes and lane 63 read whatever: nobody uses it.
   const int addrA = ((L - W) & 63) * 4;
   const int addrB = (live && aa < W - 1 ? ((L - W + 1) & 63) : 63) * 4;
+  // lane L-1 = (i, a-1), or lane 63 (sentinels) where a-1 leaves the band
+  const int addrC = ((live && aa > 0) ? L - 1 : 63) * 4;
   const bool a_first = (aa == 0);
   const int lane_cap = a_first ? SENT : 0x7fffffff;  // min() with it = "sentinel where a-1 leaves the band"
   int32_t* const lay = A.layers + pd.layer_off;
@@ -141,7 +143,8 @@ __global__ void __launch_bounds__(64 * TW * PPW, 3) fill_affine_slim_kernel(cons
   int dB[4][W];              // GMY, H3M[0..2] from (i-1,a+1): age 2
   int dC[2][W];              // GYM, GYX from (i,a-1): age 2
   int selfv[4][W];           // GYY, H3Y[0..2] of this lane's previous column
-  int pubC[W][8];            // GYM, GYX, H2M[0..2], H2X[0..2] of the previous column, for lane L+1
+  int pubC[W][8];            // GYM, GYX, H2M[0..2], H2X[0..2] of the previous column, for lane L+1 (DPP form only)
+  int inC[W][8];             // ... as received from lane L-1 (bpermute form: loop-carried, exchanged at the end of a step)
   int inA[W][4], inB[W][8];  // what (i-1,a) and (i-1,a+1) derived one step ago (loop-carried: exchanged at the end of a step)
 #pragma unroll
   for (int bb = 0; bb < W; ++bb) {
@@ -150,7 +153,7 @@ __global__ void __launch_bounds__(64 * TW * PPW, 3) fill_affine_slim_kernel(cons
 #pragma unroll
     for (int x = 0; x < 4; ++x) dB[x][bb] = selfv[x][bb] = inA[bb][x] = SENT;
 #pragma unroll
-    for (int x = 0; x < 8; ++x) pubC[bb][x] = inB[bb][x] = SENT;
+    for (int x = 0; x < 8; ++x) pubC[bb][x] = inB[bb][x] = inC[bb][x] = SENT;
   }
   const uint32_t ring_lds = __builtin_amdgcn_readfirstlane(
       (uint32_t)(uintptr_t)(__attribute__((address_space(3))) int32_t*)smem) + wv * GF::RING_DW * 4;
@@ -268,8 +271,8 @@ __global__ void __launch_bounds__(64 * TW * PPW, 3) fill_affine_slim_kernel(cons
 
     // ---- 1. lane L-1 = (i, a-1) hands its values over in registers: DPP wave shift fused with the cap (s_nop 1: the
     //         wait states a DPP read needs, see fill_affine_kernel)
-    int inC[W][8];
     auto read_dpp = [&](int r) __attribute__((always_inline)) {
+      if (!BIALIGN_SLIM_DPP) return;
       if (r + 1 < W) {
         asm("s_nop 1\n\t"
             "v_min_i32_dpp %0, %8, %16 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
@@ -333,6 +336,7 @@ __global__ void __launch_bounds__(64 * TW * PPW, 3) fill_affine_slim_kernel(cons
     int pk_base = 0, pk_acc = pk_all, pk_e[PACKED ? ND : 1];  // (the OR of the offsets runs on across the steps of a block)
     int h2y[3] = {SENT, SENT, SENT};
     int defer[3] = {SENT, SENT, SENT};  // GXM, GXX, GXY of the previous point: their registers are busy for one more point
+    int deferC[3] = {SENT, SENT, SENT}; // H2M[0..2] of the previous point, likewise
 #pragma unroll
     for (int bb = 0; bb < W; ++bb) {
       if (bb + 1 < W) read_dpp(bb + 1 < W ? bb + 1 : 0);
@@ -529,12 +533,14 @@ __global__ void __launch_bounds__(64 * TW * PPW, 3) fill_affine_slim_kernel(cons
         Gd[0][v] = imax(H2[0][v], bmg);
         Gd[1][v] = imax(H2[1][v], bmg);
       }
+      if (BIALIGN_SLIM_DPP) {
       pubC[bb][0] = Gd[0][2];
       pubC[bb][1] = Gd[0][1];
 #pragma unroll
       for (int u = 0; u < 3; ++u) {
         pubC[bb][2 + u] = H2[u][2];
         pubC[bb][5 + u] = H2[u][1];
+      }
       }
       selfv[0][bb] = Gd[0][0];
 #pragma unroll
@@ -550,8 +556,26 @@ __global__ void __launch_bounds__(64 * TW * PPW, 3) fill_affine_slim_kernel(cons
       dmov(dB[0][bb], inB[bb][0]);
 #pragma unroll
       for (int v = 0; v < 3; ++v) dmov(dB[1 + v][bb], inB[bb][2 + v]);
-      dC[0][bb] = inC[bb][0];
-      dC[1][bb] = inC[bb][1];
+      if (BIALIGN_SLIM_DPP) {
+        dC[0][bb] = inC[bb][0];
+        dC[1][bb] = inC[bb][1];
+      } else {
+        // BIALIGN_SLIM_DPP=0 (measured, not shipped: 48.7 against 46.6 ms -- the LDS pipe has no room for 21 more
+        // instructions per step): lane L-1's values travel like the rows'.  GYM, GYX wait one more step in dC; H2X is
+        // used in this point only; H2M still serves the next point of this step and follows one point later
+        dmov(dC[0][bb], inC[bb][0]);
+        dmov(dC[1][bb], inC[bb][1]);
+        inC[bb][0] = bperm(addrC, Gd[0][2]);
+        inC[bb][1] = bperm(addrC, Gd[0][1]);
+#pragma unroll
+        for (int u = 0; u < 3; ++u) inC[bb][5 + u] = bperm(addrC, H2[u][1]);
+        if (bb >= 1) {
+#pragma unroll
+          for (int u = 0; u < 3; ++u) inC[bb >= 1 ? bb - 1 : 0][2 + u] = bperm(addrC, deferC[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 3; ++u) deferC[u] = H2[u][2];
+      }
       // exchange (for the next step): what lanes (i-1, a) and (i-1, a+1) derived for this band column.  The registers
       // of GXM, GXX (inA[.][2..3]) and GXY (inB[.][1]) still serve the NEXT point of this step: those three follow
       // one point later.

@@ -53,6 +53,10 @@
 #define BIALIGN_OPT2 1  // packer reuses the finalisation's "no valid case" test
 #endif
 
+#ifndef BIALIGN_SLIM_DPP  // fill_affine_slim_kernel: 1 = lane L-1's values by DPP (as fill_affine_kernel), 0 = by ds_bpermute
+#define BIALIGN_SLIM_DPP 1  // like the rows': 21 VALU less, 21 LDS instructions more per step -- and 4.5 % slower (48.7 vs 46.6 ms)
+#endif
+
 #ifdef BIALIGN_WPE  // experiment: cap the affine sweep's registers so that this many waves fit a SIMD
 #define BIALIGN_WPE_ATTR __attribute__((amdgpu_waves_per_eu(BIALIGN_WPE, BIALIGN_WPE)))
 #else

@@ -99,6 +99,33 @@ def test_two_wave_kernels_stay_covered(team, monkeypatch):
     check(synth.protein_pair(4250, 300, 330), dict(synth.PROTEIN_PARAMS))
 
 
+@pytest.mark.parametrize("team,npairs", [("3", 7), ("2", 13), ("6", 3)])
+def test_slim_workgroups_of_ragged_pairs(team, npairs, monkeypatch):
+    """fill_affine_slim_kernel: a workgroup holds 12 / team pairs of different lengths, the last workgroup fewer than
+    that (its surplus waves leave after the staging barrier): scores, traces and one pair's layers against the oracle."""
+    from oracle import oracle
+    from bialign_amd.batch import make_batch
+    from bialign_amd.engine import trace_codes_to_columns
+    monkeypatch.setenv("BIALIGN_TEAM", team)
+    big = 560 if team == "6" else 300
+    pairs = [synth.protein_pair(4270 + t, big + 23 * t, big + 140 - 11 * t) for t in range(npairs)]
+    params = dict(synth.PROTEIN_PARAMS)
+    b = make_batch(pairs, params)
+    b.run()
+    assert b.timing()["packed_records"] and b.timing()["waves_per_pair"] == int(team)
+    scores = b.scores()
+    traces, ok = b.traces()
+    for t in (0, npairs // 2, npairs - 1):
+        ref = oracle.solve(*pairs[t], params)
+        assert int(scores[t]) == ref["score"] and bool(ok[t]) == ref["complete"]
+        assert trace_codes_to_columns(traces[t]) == oracle.trace_to_lists(ref["trace"])
+    t = npairs - 1
+    n, m = len(pairs[t][0]), len(pairs[t][1])
+    for g, e in zip(oracle.band_values(b.dump_layers(t), n, m, 1), oracle.band_values(oracle.solve(*pairs[t], params)["layers"], n, m, 1)):
+        np.testing.assert_array_equal(g, e)
+    b.close()
+
+
 def test_slim_and_two_wave_kernels_agree_on_a_batch(monkeypatch):
     """A ragged batch through both s=1 packed sweeps: identical scores, traces and layers."""
     from bialign_amd.batch import make_batch
