@@ -25,12 +25,18 @@ while time.time() < t_end:
     hi = (420 if big else 90) if s <= 5 else (60 if big else 28)
     if s == 2 and big and rng.random() < 0.5:
         hi, npairs = 900, min(npairs, 2)                              # room for eight-wave workgroups and teams of them
-    shapes = [(int(rng.integers(1, hi)), int(rng.integers(1, hi))) for _ in range(npairs)]
+    # beyond the tiled band: full storage, or (round 3, affine only) score-only from the ring of derived values
+    mode = ["full", "score_only", "lean_trace"][int(rng.integers(0, 3))] if s <= 5 else ("score_only" if affine and rng.random() < 0.4 else "full")
+    # (3, 6, 12 and -- at max_shift 1 -- 2: the three-waves-per-SIMD kernel where the pairs' period admits the team)
+    team = str(rng.choice(["", "", "2", "3", "4", "6", "8", "12", "x2", "x3", "x5", "x8", "h1", "h2"]))
+    lo = 1
+    if s == 1 and affine and big and team in ("2", "3", "6", "12") and rng.random() < (0.15 if team == "12" else 0.7):
+        lo, hi = {"2": (270, 420), "3": (290, 420), "6": (500, 560), "12": (940, 1000)}[team]  # every pair long enough for the team
+        npairs = 1 if team == "12" else min(npairs, 3)
+    shapes = [(int(rng.integers(lo, hi)), int(rng.integers(lo, hi))) for _ in range(npairs)]
     pairs = [synth.protein_pair(int(rng.integers(1 << 30)), n, m) for n, m in shapes]
     dense = rng.random() < 0.3
     tabs = [rng.integers(-500, 1500, size=(n, m)).astype(np.int32) for n, m in shapes] if dense else None
-    mode = ["full", "score_only", "lean_trace"][int(rng.integers(0, 3))] if s <= 5 else "full"
-    team = str(rng.choice(["", "", "2", "4", "8", "x2", "x3", "x5", "x8", "h1", "h2"]))
     os.environ.pop("BIALIGN_TEAM", None)
     if team:
         os.environ["BIALIGN_TEAM"] = team
