@@ -74,7 +74,9 @@ TeamShape team_shape(const bialign_batch* b, int first, int count, int xcu_resid
   }
   // in-workgroup: the smallest team that (nearly) maximises the waves running at once, given
   // how many workgroups of that size a CU holds (LDS, registers)
-  const int waves_cu_regs = !b->affine ? 16 : (b->S <= 1 ? 12 : (b->S == 2 ? 8 : 4));
+  // (registers: the one-layer kernels and the affine s=0 kernel (56) fit four waves per SIMD -- and four are measurably
+  //  better than three for them, tools/occupancy_probe.py --, affine s=1 188-200 = two, counted as three here since round 1)
+  const int waves_cu_regs = !b->affine ? 16 : (b->S == 0 ? 16 : (b->S == 1 ? 12 : (b->S == 2 ? 8 : 4)));
   auto concurrent = [&](int t) {
     const size_t lds = (lds_of(t) + 1023) / 1024 * 1024;
     const int wg_cu = (int)std::min<size_t>((160 * 1024) / lds, (size_t)(waves_cu_regs / t));

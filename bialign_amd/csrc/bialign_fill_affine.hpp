@@ -380,7 +380,7 @@ __global__ void __launch_bounds__(64 * TW) BIALIGN_WPE_ATTR fill_affine_kernel(c
             for (int d = 0; d < 4 * GF::NP; ++d) {
               const int h = PK_::hw(d < ND ? d : 0);
               const unsigned word = (unsigned)raw[d < ND && d != PK_::ANCHOR ? h >> 1 : 0];
-              const unsigned e = d == PK_::ANCHOR ? 0x8000u : ((h & 1) ? word >> 16 : word & 0xffffu);
+              const unsigned e = d == PK_::ANCHOR ? 0x8000u : PK_::offset_of((h & 1) ? word >> 16 : word & 0xffffu, raw[0]);
               const int v = raw[0] + (int)e;
               dec[d] = d >= ND ? 0 : (pack_corner(W, d % 9, d / 9) ? (e == 0xffffu ? NEG : v) : v);
             }
@@ -420,7 +420,7 @@ __global__ void __launch_bounds__(64 * TW) BIALIGN_WPE_ATTR fill_affine_kernel(c
       for (int d = 0; d < ND; ++d) {
         const int h = PK_::hw(d);
         const unsigned word = (unsigned)raw[d != PK_::ANCHOR ? h >> 1 : 0];
-        const unsigned e = d == PK_::ANCHOR ? 0x8000u : ((h & 1) ? word >> 16 : word & 0xffffu);
+        const unsigned e = d == PK_::ANCHOR ? 0x8000u : PK_::offset_of((h & 1) ? word >> 16 : word & 0xffffu, raw[0]);
         const int v = raw[0] + (int)e;
         ghostM[d] = pack_corner(W, d % 9, d / 9) ? (e == 0xffffu ? NEG : v) : v;
       }
@@ -528,7 +528,7 @@ __global__ void __launch_bounds__(64 * TW) BIALIGN_WPE_ATTR fill_affine_kernel(c
 
     // ---- 3. the W lattice points of this (i, j, a)
     int outv[ND];
-    int pk_base = 0, pk_acc = pk_all, pk_e[PACK ? ND : 1];  // packed records: base, OR of the stored offsets (running on across a block), the offsets
+    int pk_base = 0, pk_min = 0, pk_max = 0, pk_or = 0, pk_e[PACK ? ND : 1];  // packed records: base, running extremes / OR of the step's offsets, what the record takes
     int h2y[3] = {SENT, SENT, SENT};  // H2[U][Y] of point bb-1 (same step, same lane)
 #pragma unroll
     for (int bb = 0; bb < W; ++bb) {
@@ -646,23 +646,53 @@ __global__ void __launch_bounds__(64 * TW) BIALIGN_WPE_ATTR fill_affine_kernel(c
         }
       }
       if (PACK && INTERIOR) {
-        // Packed record (Pack<S>): dword 0 = base, then the offsets of all values but the anchor (whose offset is
-        // 0x8000 by construction) as unsigned halfwords.  The OR of all offsets stored by lanes that hold lattice
-        // points is range-checked at the end of the step.
-        if (bb == 0) pk_base = M[8] - 0x8000;
-#pragma unroll
-        for (int q = 0; q < 9; ++q) {
-          if (bb * 9 + q == PK_::ANCHOR) continue;
-          int e = M[q] - pk_base;
-          if (pack_corner(W, q, bb)) {  // 0xffff is the -2^30 mark here: a finite value must stay below it
-            // (a finite value that happens to equal -2^30 is not marked: its offset then fails the range check)
-            const bool ng = (BIALIGN_OPT2 != 0 && (BIALIGN_OPT & 2) != 0) ? isneg[q] : M[q] == NEG;
-            pk_acc |= ng ? 0 : e + 1;
-            e = ng ? 0xffff : e;
-          } else {
-            pk_acc |= e;
+        // Packed record (Pack<S>): dword 0 = base, then the low halves of all values but the anchor (whose offset is
+        // 0x8000 by construction).  The range of what the lanes that hold lattice points store is checked through the
+        // running minimum and maximum of the step.
+        if (PK_::LOWHALF) {
+          if (bb == 0) {
+            pk_base = M[8] - 0x8000;
+            pk_min = pk_max = M[8];
           }
-          pk_e[PACK ? bb * 9 + q : 0] = e;
+          {
+            int xs[9];
+            int nx = 0;
+  #pragma unroll
+            for (int q = 0; q < 9; ++q) {
+              if (bb * 9 + q == PK_::ANCHOR) continue;
+              int x = M[q];
+              if (pack_corner(W, q, bb)) {  // offset 0xffff is the -2^30 mark here: base + 0xffff stands in for the value, in the
+                // record and in the running minimum alike (it is the largest value a record can hold; a finite value that
+                // happens to equal -2^30 is not marked and fails the range check)
+                const bool ng = (BIALIGN_OPT2 != 0 && (BIALIGN_OPT & 2) != 0) ? isneg[q] : M[q] == NEG;
+                x = ng ? pk_base + 0xffff : x;
+              }
+              pk_e[PACK ? bb * 9 + q : 0] = x;  // (the record takes the low half)
+              xs[nx++] = x;
+            }
+            // range: every stored value within [base, base + 0xfffe]  <=>  min - base >= 0 and max - base + 1 <= 0xffff;
+            // the maximum of a point's nine values is its G[M][M], computed below anyway
+  #pragma unroll
+            for (int t = 0; t + 1 < nx; t += 2) pk_min = imin(imin(pk_min, xs[t]), xs[t + 1]);
+            if (nx & 1) pk_min = imin(pk_min, xs[nx - 1]);
+          }
+        } else {  // offsets value - base in the record; their OR is the range check
+          if (bb == 0) pk_base = M[8] - 0x8000;
+          int acc = 0;
+#pragma unroll
+          for (int q = 0; q < 9; ++q) {
+            if (bb * 9 + q == PK_::ANCHOR) continue;
+            int e = M[q] - pk_base;
+            if (pack_corner(W, q, bb)) {  // 0xffff is the -2^30 mark here: a finite value must stay below it
+              const bool ng = (BIALIGN_OPT2 != 0 && (BIALIGN_OPT & 2) != 0) ? isneg[q] : M[q] == NEG;
+              acc |= ng ? 0 : e + 1;
+              e = ng ? 0xffff : e;
+            } else {
+              acc |= e;
+            }
+            pk_e[PACK ? bb * 9 + q : 0] = e;
+          }
+          pk_or |= acc;
         }
         if (do_store) {
 #pragma unroll
@@ -697,7 +727,6 @@ __global__ void __launch_bounds__(64 * TW) BIALIGN_WPE_ATTR fill_affine_kernel(c
             }
           }
         }
-        if (bb == W - 1) pk_all = act_row ? pk_acc : 0;  // rows outside the lattice hold don't-care values; range-checked once per block
       }
       if (do_store && !(PACK && INTERIOR)) {
 #pragma unroll
@@ -765,6 +794,13 @@ __global__ void __launch_bounds__(64 * TW) BIALIGN_WPE_ATTR fill_affine_kernel(c
           H3[1][v] = fX(M[v], M[3 + v], M[6 + v], beta);
           Gd[0][v] = fY(H2[0][v], H2[1][v], H2[2][v], beta);
           Gd[1][v] = fX(H2[0][v], H2[1][v], H2[2][v], beta);
+        }
+      }
+      if (PACK && INTERIOR) {
+        pk_max = imax(pk_max, Gd[2][2]);
+        if (bb == W - 1) {  // rows outside the lattice hold don't-care values; the OR runs on across steps, tested every 16
+          const int acc = PK_::LOWHALF ? (pk_all | (pk_max - pk_base + 1) | (pk_min - pk_base)) : (pk_all | pk_or);
+          pk_all = act_row ? acc : 0;
         }
       }
       // publish (all reads of this step were issued above, LDS keeps order)

@@ -242,7 +242,7 @@ __global__ void __launch_bounds__(64 * TW * PPW, 3) fill_affine_slim_kernel(cons
             for (int d = 0; d < 4 * GF::NP; ++d) {
               const int h = PK_::hw(d < ND ? d : 0);
               const unsigned word = (unsigned)raw[d < ND && d != PK_::ANCHOR ? h >> 1 : 0];
-              const unsigned e = d == PK_::ANCHOR ? 0x8000u : ((h & 1) ? word >> 16 : word & 0xffffu);
+              const unsigned e = d == PK_::ANCHOR ? 0x8000u : PK_::offset_of((h & 1) ? word >> 16 : word & 0xffffu, raw[0]);
               const int v = raw[0] + (int)e;
               dec[d] = d >= ND ? 0 : (pack_corner(W, d % 9, d / 9) ? (e == 0xffffu ? NEG : v) : v);
             }
@@ -333,7 +333,7 @@ __global__ void __launch_bounds__(64 * TW * PPW, 3) fill_affine_slim_kernel(cons
 
     // ---- 3. the W lattice points of this (i, j, a)
     int outv[PACKED ? 1 : ND];
-    int pk_base = 0, pk_acc = pk_all, pk_e[PACKED ? ND : 1];  // (the OR of the offsets runs on across the steps of a block)
+    int pk_base = 0, pk_min = 0, pk_max = 0, pk_e[PACKED ? ND : 1];  // packed records: base, running extremes, the values
     int h2y[3] = {SENT, SENT, SENT};
     int defer[3] = {SENT, SENT, SENT};  // GXM, GXX, GXY of the previous point: their registers are busy for one more point
     int deferC[3] = {SENT, SENT, SENT}; // H2M[0..2] of the previous point, likewise
@@ -443,22 +443,33 @@ __global__ void __launch_bounds__(64 * TW * PPW, 3) fill_affine_slim_kernel(cons
         }
       }
       if (PACKED) {
-        // packed record (Pack<S>): dword 0 = base, then the offsets of all values but the anchor as unsigned halfwords; a
-        // piece of it leaves as soon as its last offset exists
-        if (bb == 0) pk_base = M[8] - 0x8000;
+        // packed record (Pack<S>): dword 0 = base, then the low halves of all values but the anchor; a piece of it leaves
+        // as soon as its last value exists
+        if (bb == 0) {
+          pk_base = M[8] - 0x8000;
+          pk_min = pk_max = M[8];
+        }
+        {
+          int xs[9];
+          int nx = 0;
 #pragma unroll
-        for (int q = 0; q < 9; ++q) {
-          if (bb * 9 + q == PK_::ANCHOR) continue;
-          int e = M[q] - pk_base;
-          if (pack_corner(W, q, bb)) {  // 0xffff is the -2^30 mark here: a finite value must stay below it
-            // (a finite value that happens to equal -2^30 is not marked: its offset then fails the range check)
-            const bool ng = BIALIGN_OPT2 ? isneg[q] : M[q] == NEG;
-            pk_acc |= ng ? 0 : e + 1;
-            e = ng ? 0xffff : e;
-          } else {
-            pk_acc |= e;
+          for (int q = 0; q < 9; ++q) {
+            if (bb * 9 + q == PK_::ANCHOR) continue;
+            int x = M[q];
+            if (pack_corner(W, q, bb)) {  // offset 0xffff is the -2^30 mark here: base + 0xffff stands in for the value, in the
+              // record and in the running minimum alike (it is the largest value a record can hold; a finite value that
+              // happens to equal -2^30 is not marked and fails the range check)
+              const bool ng = BIALIGN_OPT2 ? isneg[q] : M[q] == NEG;
+              x = ng ? pk_base + 0xffff : x;
+            }
+            pk_e[PACKED ? bb * 9 + q : 0] = x;  // (the record takes the low half)
+            xs[nx++] = x;
           }
-          pk_e[PACKED ? bb * 9 + q : 0] = e;
+          // range: every stored value within [base, base + 0xfffe]  <=>  min - base >= 0 and max - base + 1 <= 0xffff;
+          // the maximum of a point's nine values is its G[M][M], computed below anyway
+#pragma unroll
+          for (int t = 0; t + 1 < nx; t += 2) pk_min = imin(imin(pk_min, xs[t]), xs[t + 1]);
+          if (nx & 1) pk_min = imin(pk_min, xs[nx - 1]);
         }
         if (do_store) {
 #pragma unroll
@@ -487,7 +498,6 @@ __global__ void __launch_bounds__(64 * TW * PPW, 3) fill_affine_slim_kernel(cons
             }
           }
         }
-        if (bb == W - 1) pk_all = act_row ? pk_acc : 0;  // rows outside the lattice hold don't-care values; range-checked once per block
       } else {
         if (do_store) {
 #pragma unroll
@@ -532,6 +542,13 @@ __global__ void __launch_bounds__(64 * TW * PPW, 3) fill_affine_slim_kernel(cons
         H3[1][v] = imax(M[3 + v], bm3);
         Gd[0][v] = imax(H2[0][v], bmg);
         Gd[1][v] = imax(H2[1][v], bmg);
+      }
+      if (PACKED) {
+        pk_max = imax(pk_max, Gd[2][2]);
+        if (bb == W - 1) {  // rows outside the lattice hold don't-care values; the OR runs on across steps, tested every 16
+          const int acc = pk_all | (pk_max - pk_base + 1) | (pk_min - pk_base);
+          pk_all = act_row ? acc : 0;
+        }
       }
       if (BIALIGN_SLIM_DPP) {
       pubC[bb][0] = Gd[0][2];
