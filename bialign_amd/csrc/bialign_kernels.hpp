@@ -39,7 +39,7 @@
 #ifndef BIALIGN_EXP
 // timing experiments only (tools/exp_build.sh; results are wrong by construction):
 // 1 = no layer stores, 2 = stores wrap inside 1 MiB per wave, 9 = no team hand-off waits, 3 = never take the
-// interior step variant, 4 = always take it
+// interior step variant, 4 = always take it, 8 = the wide-band affine sweep stamps the phases of a level (tools/wide_phases.py)
 #define BIALIGN_EXP 0
 #endif
 #ifndef BIALIGN_PADMAX

@@ -86,24 +86,56 @@ __device__ __forceinline__ void wide_store(int32_t* p, int v) {
   __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // global_store_dword ... sc1: write-through
 }
 
-// Close a level: every part's stores are acknowledged, then all parts of the pair have said so.
-__device__ __forceinline__ void wide_level_sync(const DeviceBatch& A, int32_t* counter, int level, int parts, bool& failed) {
+#if BIALIGN_EXP == 8
+__device__ long long wide_exp_polls, wide_exp_own;  // (every part's thread 0 adds to them: read for part 0 only by dividing, roughly)
+#endif
+// Close a level: every part's stores are acknowledged, then all parts of the pair have said so -- each in a word of its
+// own (flags[part] = levels closed; a write-through store, nothing to serialise), and thread t of every part watches
+// part t's word: one round trip sees all of them, where a shared counter took one atomic per part on one address.
+__device__ __forceinline__ void wide_level_sync(const DeviceBatch& A, int32_t* flags, int level, int part, int parts, bool& failed) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (parts > 1) {
-    if (threadIdx.x == 0 && !failed) {
-      __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const int need = (level + 1) * parts;
-      for (int spin = 0; __hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need; ++spin) {
+    if (threadIdx.x == 0) __hip_atomic_store(flags + part, level + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((int)threadIdx.x < parts && !failed) {
+#if BIALIGN_EXP == 8
+      const long long ts0 = __builtin_amdgcn_s_memtime();
+#endif
+      for (int spin = 0; __hip_atomic_load(flags + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= level; ++spin) {
+#if BIALIGN_EXP == 8
+        if (threadIdx.x == 0) wide_exp_polls += 1;
+#endif
         if (spin > A.spin_limit) {  // a partner was never scheduled: fail fast, the host recovers
           atomicOr(A.errflag, 1);
           failed = true;
           break;
         }
-        __builtin_amdgcn_s_sleep(8);
+        __builtin_amdgcn_s_sleep(2);
       }
+#if BIALIGN_EXP == 8
+      if (threadIdx.x == 0) wide_exp_own += __builtin_amdgcn_s_memtime() - ts0;  // thread 0 watches part 0 (its own part for part 0)
+#endif
     }
     __syncthreads();
+  }
+}
+
+// A pair's sequence / class codes and the score tables, staged in LDS when they fit (the two dependent lookups of
+// mu1 and mu2 are then off the level's chain of memory round trips); else the context keeps its global pointers.
+constexpr int WIDE_STAGE_CODES = 8192, WIDE_STAGE_TAB = 1024;
+struct WideStage {
+  uint8_t codes[4][WIDE_STAGE_CODES];
+  int32_t tab[2][WIDE_STAGE_TAB];
+};
+__device__ __forceinline__ void wide_stage(WideCtx& c, WideStage& st) {
+  if (c.n <= WIDE_STAGE_CODES && c.m <= WIDE_STAGE_CODES && c.k1 * c.k1 <= WIDE_STAGE_TAB && c.k2 * c.k2 <= WIDE_STAGE_TAB) {
+    for (int t = threadIdx.x; t < c.n; t += WIDE_THREADS) { st.codes[0][t] = c.sa[t]; st.codes[1][t] = c.ca[t]; }
+    for (int t = threadIdx.x; t < c.m; t += WIDE_THREADS) { st.codes[2][t] = c.sb[t]; st.codes[3][t] = c.cb[t]; }
+    for (int t = threadIdx.x; t < c.k1 * c.k1; t += WIDE_THREADS) st.tab[0][t] = c.s1[t];
+    for (int t = threadIdx.x; t < c.k2 * c.k2; t += WIDE_THREADS) st.tab[1][t] = c.s2[t];
+    __syncthreads();
+    c.sa = st.codes[0]; c.ca = st.codes[1]; c.sb = st.codes[2]; c.cb = st.codes[3];
+    c.s1 = st.tab[0]; c.s2 = st.tab[1];
   }
 }
 
@@ -113,22 +145,19 @@ __device__ __forceinline__ void wide_level_sync(const DeviceBatch& A, int32_t* c
 //   G[U][V] = f_U(H2[.][V]),  H2[U][V] = f_V(M[(U,.)]),  H3[U][V] = f_U(M[(.,V)]),   f_T(v) = max_h(open(h,T) + v[h])
 // into a ring of the last WIDE_RING levels (a predecessor lowers D by 1..4), and a target state (U,V) then needs ONE
 // value from each of three predecessor cells -- G[U][V](q-(U,V)), H2[U][V](q-(0,0,V)), H3[U][V](q-(U,0,0)) -- instead
-// of nine, three and three layer values: 27 four-byte loads per point instead of 135 (round 2), and vector stores
-// (16 bytes, write-through) instead of nine scalar ones.  The ring is indexed [D mod WIDE_RING][i][a][b/2] (within a
-// level b has one parity); a slot is 28 dwords (16-byte aligned): G at 3U+V, H2 at 9+3V+U (fixed V contiguous), H3 at 18+3U+V.
+// of nine, three and three layer values: 27 four-byte loads per point instead of 135 (round 2).  The ring is a
+// structure of arrays, [D mod WIDE_RING][component][i][a][b/2] (within a level b has one parity; components: G at 3U+V,
+// H2 at 9+3V+U, H3 at 18+3U+V): neighbouring threads hold neighbouring (i, a, b), and a predecessor by a fixed offset
+// is a neighbour again, so one load or store instruction of a wave touches four or five 64-byte lines (making i the
+// fastest index instead -- runs of 64 -- was measured and is 3-10 % slower: the score lookups then diverge) -- with the
+// 28-dword slot per point that the first version of this sweep used it touched sixty-four, and the level was bound by
+// the address path of the CU (27 gathers + 7 scattered stores per wave), not by latency.
 // With A.wide_score_only the layers themselves are not stored at all: the last level's one point writes the score.
 // ---------------------------------------------------------------------------
-constexpr int WIDE_RING = 5, WIDE_SLOT = 28;
+constexpr int WIDE_RING = 5, WIDE_SLOT = 27;
 __host__ __device__ inline int64_t wide_ring_level_dwords(int n, int S) {
   const int64_t W = 2 * S + 1;
   return (int64_t)(n + 1) * W * ((W + 1) / 2) * WIDE_SLOT;
-}
-__device__ __forceinline__ void wide_store4(int32_t* p, int a, int b, int c, int d) {
-  v4i v;
-  v.x = a; v.y = b; v.z = c; v.w = d;
-  // write-through; p is 16-byte aligned.  s_nop 1: a store of more than 8 bytes must not be followed at once by a write of
-  // its data registers, and the hazard recogniser does not look inside asm (as in store_chunk of the tiled sweep)
-  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
 }
 // f_T for target half Y, X, M over the values of source halves (y, x, m); exact for any sign of beta
 __device__ __forceinline__ int wfY(int y, int x, int m, int beta) { return max(y, beta + max(x, m)); }
@@ -149,17 +178,26 @@ __global__ void __launch_bounds__(WIDE_THREADS) fill_wide_affine_kernel(const De
   c.lay = A.layers + pd.layer_off;
   const int n = c.n, m = c.m, W = c.W, HW = (W + 1) / 2;
   const int beta = c.beta, gamma = c.gamma, delta = c.delta;
-  int32_t* const counter = A.prog + (int64_t)slot * PROG_WORDS;
+  int32_t* const flags = A.prog + (int64_t)slot * PROG_WORDS;  // [parts] levels closed, zeroed per launch
   int32_t* const ring = A.wide_ring + A.wide_ring_off[slot];
-  const int64_t lvl = wide_ring_level_dwords(n, S);
+  __shared__ WideStage stage;
+  wide_stage(c, stage);
+  const int64_t LV = (int64_t)(n + 1) * W * HW, lvl = wide_ring_level_dwords(n, S);  // points per level, dwords per level (27 LV)
   const bool keep_layers = !A.wide_score_only;
-  bool failed = false;  // (thread 0: a level barrier timed out, no further waits)
+  bool failed = false;  // (a level barrier timed out for this thread: no further waits)
 
-  // ring slot of lattice point (i, a, b) of level Dq
-  auto rslot = [&](int Dq, int i, int aa, int bb) -> int32_t* {
-    return ring + (Dq % WIDE_RING) * lvl + ((int64_t)(i * W + aa) * HW + (bb >> 1)) * WIDE_SLOT;
+  // component 0 of lattice point (i, a, b) in the ring level at `base`; component v lies v * LV dwords further
+  auto rpoint = [&](int32_t* base, int i, int aa, int bb) -> int32_t* {
+    return base + (int64_t)(i * W + aa) * HW + (bb >> 1);
   };
+#if BIALIGN_EXP == 8  // timing experiment: where a level's time goes (thread 0 of part 0 prints the averages)
+  long long tph[5] = {0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
+  auto stamp = [&](int ph) { const long long t = __builtin_amdgcn_s_memtime(); tph[ph] += t - tlast; tlast = t; };
+#endif
   for (int D = 0; D <= 2 * (n + m); ++D) {
+    int32_t* rb[WIDE_RING];  // ring levels of D, D-1, .. D-4
+#pragma unroll
+    for (int d = 0; d < WIDE_RING; ++d) rb[d] = ring + ((D - d + WIDE_RING) % WIDE_RING) * lvl;
     wide_for_level(c, D, part, parts, [&](int i, int j, int k, int l, int aa, int bb) {
       int M[9];
       if (D == 0) {  // pyx:483-485
@@ -176,7 +214,7 @@ __global__ void __launch_bounds__(WIDE_THREADS) fill_wide_affine_kernel(const De
           const int o0 = (code >> 3) & 1, o1 = (code >> 2) & 1, o2 = (code >> 1) & 1, o3 = code & 1;
           const int pi = i - o0, pj = j - o1, pk = k - o2, pl = l - o3;
           ok[code] = c.valid(pi, pj, pk, pl);
-          src[code] = ok[code] ? rslot(D - o0 - o1 - o2 - o3, pi, pk - pi + S, pl - pj + S) : ring;
+          src[code] = ok[code] ? rpoint(rb[o0 + o1 + o2 + o3], pi, pk - pi + S, pl - pj + S) : ring;
         }
         int g[9], h2[9], h3[9];  // [3*hU + hV]: the one value each group contributes to target state (hU, hV)
 #pragma unroll
@@ -185,12 +223,17 @@ __global__ void __launch_bounds__(WIDE_THREADS) fill_wide_affine_kernel(const De
           for (int hV = 0; hV < 3; ++hV) {
             const int u0 = hU >= 1, u1 = hU != 1, v0 = hV >= 1, v1 = hV != 1;
             const int c1 = u0 * 8 + u1 * 4 + v0 * 2 + v1, c2 = v0 * 2 + v1, c3 = u0 * 8 + u1 * 4;
-            g[3 * hU + hV] = __hip_atomic_load(src[c1] + 3 * hU + hV, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            h2[3 * hU + hV] = __hip_atomic_load(src[c2] + 9 + 3 * hV + hU, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            h3[3 * hU + hV] = __hip_atomic_load(src[c3] + 18 + 3 * hU + hV, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            g[3 * hU + hV] = __hip_atomic_load(src[c1] + (3 * hU + hV) * LV, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            h2[3 * hU + hV] = __hip_atomic_load(src[c2] + (9 + 3 * hV + hU) * LV, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            h3[3 * hU + hV] = __hip_atomic_load(src[c3] + (18 + 3 * hU + hV) * LV, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           }
         }
         const int mu1 = c.mu1(i, j), mu2 = c.mu2(k, l);
+#if BIALIGN_EXP == 8
+        stamp(0);  // address arithmetic, loads issued
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        stamp(1);  // loads back
+#endif
 #pragma unroll
         for (int hU = 0; hU < 3; ++hU) {
 #pragma unroll
@@ -226,19 +269,22 @@ __global__ void __launch_bounds__(WIDE_THREADS) fill_wide_affine_kernel(const De
         G[1][v] = wfX(H2[0][v], H2[1][v], H2[2][v], beta);
         G[2][v] = wfM(H2[0][v], H2[1][v], H2[2][v]);
       }
-      int32_t* r = rslot(D, i, aa, bb);
-      wide_store4(r + 0, G[0][0], G[0][1], G[0][2], G[1][0]);
-      wide_store4(r + 4, G[1][1], G[1][2], G[2][0], G[2][1]);
-      wide_store4(r + 8, G[2][2], H2[0][0], H2[1][0], H2[2][0]);       // H2 at 9 + 3V + U
-      wide_store4(r + 12, H2[0][1], H2[1][1], H2[2][1], H2[0][2]);
-      wide_store4(r + 16, H2[1][2], H2[2][2], H3[0][0], H3[0][1]);     // H3 at 18 + 3U + V
-      wide_store4(r + 20, H3[0][2], H3[1][0], H3[1][1], H3[1][2]);
-      wide_store4(r + 24, H3[2][0], H3[2][1], H3[2][2], 0);
+      int32_t* r = rpoint(rb[0], i, aa, bb);
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+#pragma unroll
+        for (int v = 0; v < 3; ++v) {
+          wide_store(r + (3 * u + v) * LV, G[u][v]);
+          wide_store(r + (9 + 3 * v + u) * LV, H2[u][v]);  // H2 at 9 + 3V + U
+          wide_store(r + (18 + 3 * u + v) * LV, H3[u][v]);
+        }
+      }
       if (keep_layers) {
-        int32_t* out = c.lay + wide_dword(m, W, 9, i, j, aa, bb, 0);
-        wide_store4(out, M[0], M[1], M[2], M[3]);
-        wide_store4(out + 4, M[4], M[5], M[6], M[7]);
-        wide_store4(out + 8, M[8], 0, 0, 0);
+        // the sweep itself never reads a layer back (its state is the ring): plain write-back stores, 16-byte aligned
+        v4i* out = reinterpret_cast<v4i*>(c.lay + wide_dword(m, W, 9, i, j, aa, bb, 0));
+        out[0] = v4i{M[0], M[1], M[2], M[3]};
+        out[1] = v4i{M[4], M[5], M[6], M[7]};
+        out[2] = v4i{M[8], 0, 0, 0};
       } else if (D == 2 * (n + m)) {  // score-only: the end cell (n,m,n,m) is all the host wants (pyx:509)
         int best = M[0];
 #pragma unroll
@@ -246,8 +292,26 @@ __global__ void __launch_bounds__(WIDE_THREADS) fill_wide_affine_kernel(const De
         A.scores[pid] = best;
       }
     });
-    wide_level_sync(A, counter, D, parts, failed);
+#if BIALIGN_EXP == 8
+    stamp(2);  // compute, stores issued
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    stamp(3);  // stores acknowledged
+#endif
+    wide_level_sync(A, flags, D, part, parts, failed);
+#if BIALIGN_EXP == 8
+    stamp(4);  // barrier
+#endif
   }
+#if BIALIGN_EXP == 8
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    const double L = 2.0 * (n + m) + 1;
+    printf("wide level phases (s_memtime ticks per level, part 0 thread 0 of %d parts): issue %.0f  loads %.0f  compute+stores %.0f  store-ack %.0f  barrier %.0f\n",
+           parts, tph[0] / L, tph[1] / L, tph[2] / L, tph[3] / L, tph[4] / L);
+    printf("  thread 0 of each part watching part 0's flag: %.1f polls, %.0f ticks per level and part\n",
+           (double)wide_exp_polls / L / parts, (double)wide_exp_own / L / parts);
+    wide_exp_polls = wide_exp_own = 0;
+  }
+#endif
 }
 
 // ---------------------------------------------------------------------------
@@ -268,8 +332,10 @@ __global__ void __launch_bounds__(WIDE_THREADS) fill_wide_linear_kernel(const De
   const int n = c.n, m = c.m, W = c.W;
   const int gamma = c.gamma, delta = c.delta, gD = gamma + delta;
   constexpr int OFF[13] = {15, 10, 5, 12, 3, 8, 4, 2, 1, 11, 7, 14, 13};  // o0*8+o1*4+o2*2+o3, generator order
-  int32_t* const counter = A.prog + (int64_t)slot * PROG_WORDS;
-  bool failed = false;  // (thread 0: a level barrier timed out, no further waits)
+  int32_t* const flags = A.prog + (int64_t)slot * PROG_WORDS;
+  bool failed = false;  // (a level barrier timed out for this thread: no further waits)
+  __shared__ WideStage stage;
+  wide_stage(c, stage);
 
   for (int D = 0; D <= 2 * (n + m); ++D) {
     wide_for_level(c, D, part, parts, [&](int i, int j, int k, int l, int aa, int bb) {
@@ -299,7 +365,7 @@ __global__ void __launch_bounds__(WIDE_THREADS) fill_wide_linear_kernel(const De
       }
       wide_store(out, best);
     });
-    wide_level_sync(A, counter, D, parts, failed);
+    wide_level_sync(A, flags, D, part, parts, failed);
   }
 }
 

@@ -90,6 +90,18 @@ def test_team_shapes(team, n, m, s, monkeypatch):
     assert got["timing"]["waves_per_pair"] == (8 * int(team[1:]) if team[0] == "h" else int(team.lstrip("x")))
 
 
+@pytest.mark.parametrize("team,n,m,s", [("x5", 1500, 300, 2), ("1", 700, 300, 2), ("4", 900, 300, 2), ("x2", 800, 300, 2),
+                                        ("x4", 900, 330, 3), ("h2", 2000, 830, 2)])
+def test_many_strips_over_a_short_period(team, n, m, s, monkeypatch):
+    """Packed sweeps at max_shift 2 and 3 whose waves go round their team 10-30 times (many strips, a short column
+    period): ghost rows unpacked from packed and from full records in every round, teams on several CUs, in one
+    workgroup, and a single wave; every layer cell, trace and score."""
+    monkeypatch.setenv("BIALIGN_TEAM", team)
+    monkeypatch.setenv("BIALIGN_PACK", "1")
+    got = check(synth.protein_pair(4300 + n, n, m), dict(synth.PROTEIN_PARAMS, max_shift=s))
+    assert got["timing"]["waves_per_pair"] == (8 * int(team[1:]) if team[0] == "h" else int(team.lstrip("x")))
+
+
 @pytest.mark.parametrize("team", ["1", "2"])
 def test_two_wave_kernels_stay_covered(team, monkeypatch):
     """BIALIGN_SLIM=0: the s=1 packed sweep on fill_affine_kernel (two waves per SIMD, LDS exchange array), which the

@@ -82,6 +82,27 @@ constexpr int UNROLL = 64, ITER = 4096;
     if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;             \
   }
 
+// the same stream with only some lanes enabled: does a SIMD skip the 16-lane passes that have no active lane?
+#define KERNEL_EXEC(NAME, OP, MASK)                                                              \
+  __global__ void __launch_bounds__(256) NAME(int* out, long long* cyc, int seed) {              \
+    int a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7; \
+    int b0 = seed, b1 = seed + 1, b2 = seed + 2, b3 = seed + 3;                                  \
+    const long long t0 = __builtin_amdgcn_s_memtime();                                           \
+    asm volatile("s_mov_b64 exec, %0" ::"s"((unsigned long long)(MASK)));                        \
+    for (int it = 0; it < ITER; ++it) {                                                          \
+      OPS8(OP) OPS8(OP) OPS8(OP) OPS8(OP) OPS8(OP) OPS8(OP) OPS8(OP) OPS8(OP)                    \
+    }                                                                                            \
+    asm volatile("s_mov_b64 exec, -1");                                                          \
+    const long long t1 = __builtin_amdgcn_s_memtime();                                           \
+    out[blockIdx.x * 256 + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;                \
+    if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;             \
+  }
+KERNEL_EXEC(k_add_exec5, ADD_U32, 0x1full)
+KERNEL_EXEC(k_add_exec16, ADD_U32, 0xffffull)
+KERNEL_EXEC(k_add_exec32, ADD_U32, 0xffffffffull)
+KERNEL_EXEC(k_max3_exec16, MAX3_I32, 0xffffull)
+KERNEL_EXEC(k_add_exec0, ADD_U32, 0ull)
+
 KERNEL(k_add_u32, ADD_U32)
 KERNEL(k_max_i32, MAX_I32)
 KERNEL(k_max3_i32, MAX3_I32)
@@ -153,7 +174,9 @@ int main() {
       {"add,max (x2)", k_mix_add_max}, {"add,add,add,max3 (x4)", k_mix_add_max3}, {"addS,addS,add,max3(x4)", k_mix_sgpr},
       {"v_add_u32_e64", k_add_e64}, {"pair: v_add + s_add", k_add_salu}, {"pair: v_max3 + s_add", k_max3_salu},
       {"trio: v_max3+s_add+s_and", k_max3_salu2}, {"pair: v_add + s_nop", k_add_nop}, {"pair: v_add + s_waitcnt", k_add_wait},
-      {"s_add_u32 alone", k_salu_only}};
+      {"s_add_u32 alone", k_salu_only},
+      {"v_add_u32 exec=5 lanes", k_add_exec5}, {"v_add_u32 exec=16 lanes", k_add_exec16}, {"v_add_u32 exec=32 lanes", k_add_exec32},
+      {"v_max3_i32 exec=16 lanes", k_max3_exec16}, {"v_add_u32 exec=0", k_add_exec0}};
   const char* only = getenv("VALU_RATE_ONLY");  // substring filter
   printf("%-26s %10s %22s %26s\n", "instruction", "waves/SIMD", "cycles/instr (a wave)", "SIMD cycles/wave-instr");
   for (auto& kd : kinds) {

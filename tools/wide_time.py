@@ -14,3 +14,11 @@ for name, pairs, s in (("1 x 300x300 s=6", [synth.rna_pair(1, 300, 300)], 6), ("
         print(f"{name:20s} {'score-only' if so else 'full      '}: fill {min(ts):8.2f} ms  tb {t['traceback_ms']:6.2f} ms  cells {b.info['cells']/1e6:8.1f} M  "
               f"{b.info['cells']/min(ts)/1e6:6.2f} Gcells/s  waves/pair {t['waves_per_pair']}", flush=True)
         b.close()
+# the one-layer recurrence (gap_opening_cost = 0, pyx:443-471) on the same path, full storage (it has no score-only form here)
+for name, pairs, s in (("1 x 1000x1000 s=6 1-layer", [synth.rna_pair(2, 1000, 1000)], 6), ("16 x len 200 s=8 1-layer", synth.rna_batch(16, 200), 8)):
+    b = make_batch(pairs, dict(synth.RNA_PARAMS, max_shift=s, gap_opening_cost=0))
+    ts = []
+    for _ in range(3):
+        b.run(); t = b.timing(); ts.append(t["fill_ms"])
+    print(f"{name:26s}: fill {min(ts):8.2f} ms  tb {t['traceback_ms']:6.2f} ms  cells {b.info['cells']/1e6:8.1f} M  {b.info['cells']/min(ts)/1e6:6.2f} Gcells/s  waves/pair {t['waves_per_pair']}", flush=True)
+    b.close()
