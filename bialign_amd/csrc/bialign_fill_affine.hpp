@@ -416,11 +416,14 @@ __global__ void __launch_bounds__(64 * TW) BIALIGN_WPE_ATTR fill_affine_kernel(c
     if (PACK && !PK_COOP && ghost_packed) {
       int raw[4 * PK_::NPC];
       GF::template fetch_pieces<PK_::NPC>(raw, ring + ghalf * GF::SLOTS, gt, aa);
+      unsigned off2[PK_::NDW];  // the two offsets each record dword holds
+#pragma unroll
+      for (int x = 1; x < PK_::NDW; ++x) off2[x] = PK_::offsets_of((unsigned)raw[x], raw[0]);
 #pragma unroll
       for (int d = 0; d < ND; ++d) {
         const int h = PK_::hw(d);
-        const unsigned word = (unsigned)raw[d != PK_::ANCHOR ? h >> 1 : 0];
-        const unsigned e = d == PK_::ANCHOR ? 0x8000u : PK_::offset_of((h & 1) ? word >> 16 : word & 0xffffu, raw[0]);
+        const unsigned word = off2[d != PK_::ANCHOR ? h >> 1 : 1];
+        const unsigned e = d == PK_::ANCHOR ? 0x8000u : ((h & 1) ? word >> 16 : word & 0xffffu);
         const int v = raw[0] + (int)e;
         ghostM[d] = pack_corner(W, d % 9, d / 9) ? (e == 0xffffu ? NEG : v) : v;
       }
@@ -528,7 +531,7 @@ __global__ void __launch_bounds__(64 * TW) BIALIGN_WPE_ATTR fill_affine_kernel(c
 
     // ---- 3. the W lattice points of this (i, j, a)
     int outv[ND];
-    int pk_base = 0, pk_min = 0, pk_max = 0, pk_or = 0, pk_e[PACK ? ND : 1];  // packed records: base, running extremes / OR of the step's offsets, what the record takes
+    int pk_base = 0, pk_min = 0, pk_max = 0, pk_e[PACK ? ND : 1];  // packed records: base, running extremes of the step's values, what the record takes
     int h2y[3] = {SENT, SENT, SENT};  // H2[U][Y] of point bb-1 (same step, same lane)
 #pragma unroll
     for (int bb = 0; bb < W; ++bb) {
@@ -649,50 +652,31 @@ __global__ void __launch_bounds__(64 * TW) BIALIGN_WPE_ATTR fill_affine_kernel(c
         // Packed record (Pack<S>): dword 0 = base, then the low halves of all values but the anchor (whose offset is
         // 0x8000 by construction).  The range of what the lanes that hold lattice points store is checked through the
         // running minimum and maximum of the step.
-        if (PK_::LOWHALF) {
-          if (bb == 0) {
-            pk_base = M[8] - 0x8000;
-            pk_min = pk_max = M[8];
-          }
-          {
-            int xs[9];
-            int nx = 0;
-  #pragma unroll
-            for (int q = 0; q < 9; ++q) {
-              if (bb * 9 + q == PK_::ANCHOR) continue;
-              int x = M[q];
-              if (pack_corner(W, q, bb)) {  // offset 0xffff is the -2^30 mark here: base + 0xffff stands in for the value, in the
-                // record and in the running minimum alike (it is the largest value a record can hold; a finite value that
-                // happens to equal -2^30 is not marked and fails the range check)
-                const bool ng = (BIALIGN_OPT2 != 0 && (BIALIGN_OPT & 2) != 0) ? isneg[q] : M[q] == NEG;
-                x = ng ? pk_base + 0xffff : x;
-              }
-              pk_e[PACK ? bb * 9 + q : 0] = x;  // (the record takes the low half)
-              xs[nx++] = x;
-            }
-            // range: every stored value within [base, base + 0xfffe]  <=>  min - base >= 0 and max - base + 1 <= 0xffff;
-            // the maximum of a point's nine values is its G[M][M], computed below anyway
-  #pragma unroll
-            for (int t = 0; t + 1 < nx; t += 2) pk_min = imin(imin(pk_min, xs[t]), xs[t + 1]);
-            if (nx & 1) pk_min = imin(pk_min, xs[nx - 1]);
-          }
-        } else {  // offsets value - base in the record; their OR is the range check
-          if (bb == 0) pk_base = M[8] - 0x8000;
-          int acc = 0;
+        if (bb == 0) {
+          pk_base = M[8] - 0x8000;
+          pk_min = pk_max = M[8];
+        }
+        {
+          int xs[9];
+          int nx = 0;
 #pragma unroll
           for (int q = 0; q < 9; ++q) {
             if (bb * 9 + q == PK_::ANCHOR) continue;
-            int e = M[q] - pk_base;
-            if (pack_corner(W, q, bb)) {  // 0xffff is the -2^30 mark here: a finite value must stay below it
+            int x = M[q];
+            if (pack_corner(W, q, bb)) {  // offset 0xffff is the -2^30 mark here: base + 0xffff stands in for the value, in the
+              // record and in the running minimum alike (it is the largest value a record can hold; a finite value that
+              // happens to equal -2^30 is not marked and fails the range check)
               const bool ng = (BIALIGN_OPT2 != 0 && (BIALIGN_OPT & 2) != 0) ? isneg[q] : M[q] == NEG;
-              acc |= ng ? 0 : e + 1;
-              e = ng ? 0xffff : e;
-            } else {
-              acc |= e;
+              x = ng ? pk_base + 0xffff : x;
             }
-            pk_e[PACK ? bb * 9 + q : 0] = e;
+            pk_e[PACK ? bb * 9 + q : 0] = x;  // (the record takes the low half)
+            xs[nx++] = x;
           }
-          pk_or |= acc;
+          // range: every stored value within [base, base + 0xfffe]  <=>  min - base >= 0 and max - base + 1 <= 0xffff;
+          // the maximum of a point's nine values is its G[M][M], computed below anyway
+#pragma unroll
+          for (int t = 0; t + 1 < nx; t += 2) pk_min = imin(imin(pk_min, xs[t]), xs[t + 1]);
+          if (nx & 1) pk_min = imin(pk_min, xs[nx - 1]);
         }
         if (do_store) {
 #pragma unroll
@@ -799,7 +783,7 @@ __global__ void __launch_bounds__(64 * TW) BIALIGN_WPE_ATTR fill_affine_kernel(c
       if (PACK && INTERIOR) {
         pk_max = imax(pk_max, Gd[2][2]);
         if (bb == W - 1) {  // rows outside the lattice hold don't-care values; the OR runs on across steps, tested every 16
-          const int acc = PK_::LOWHALF ? (pk_all | (pk_max - pk_base + 1) | (pk_min - pk_base)) : (pk_all | pk_or);
+          const int acc = pk_all | (pk_max - pk_base + 1) | (pk_min - pk_base);
           pk_all = act_row ? acc : 0;
         }
       }

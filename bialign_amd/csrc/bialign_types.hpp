@@ -105,9 +105,9 @@ struct Rec {
 // layer values is either exactly -2^30 at one of six compile-time-known (state, b) positions
 // (can_be_empty<W>) or lies within a few thousand of the lane's first value, so the lane record shrinks
 // from ND dwords to  base + (ND - 1) halfwords  (base = M[(1,1,1,1)] of the lane's first point - 0x8000, so
-// THAT value's offset is 0x8000 by construction and is not stored).  A halfword is the offset value - base or
-// (Pack<S>::LOWHALF, round 3) the LOW HALF OF THE VALUE ITSELF -- no subtraction per value in the sweep: the
-// offset is then (halfword - low half of base) mod 2^16; either way exact while 0 <= value - base < 2^16;
+// THAT value's offset is 0x8000 by construction and is not stored).  A halfword is the LOW HALF OF THE VALUE ITSELF
+// (round 3; round 2 stored the offset value - base) -- no subtraction per value in the sweep: the
+// offset is (halfword - low half of base) mod 2^16, exact while 0 <= value - base < 2^16;
 // offset 0xffff at a can_be_empty position = -2^30: 14 dwords instead of 27 at s=1 (round 2 stored all ND offsets: 16),
 // 24 instead of 45 at s=2, 32 instead of 63 at s=3 (36 in round 2).  The sweep verifies the range of every offset it stores; the first one that does
 // not fit raises the device flag and the host repeats the batch with full records.  All other steps
@@ -174,13 +174,21 @@ struct Pack {
     const int64_t f = full_records(G, P, m);
     return (G - f) * RECDW + f * R_::RECDW;
   }
-  // What a halfword holds: the low half of the value itself (LOWHALF; the sweep then packs without a subtraction per value
-  // and checks the range through a running minimum and maximum) or the offset value - base.  The first saves the s=1
-  // sweeps 2.5 % (47.1 -> 45.9 ms at the headline shape); at s=2 the ghost row is decoded by every lane in every step
-  // and the extra subtraction there costs what the encoder saves and more (config 4: 147 -> 151 ms): offsets stay.
-  static constexpr bool LOWHALF = S != 2;
+  // A halfword holds the LOW HALF OF THE VALUE ITSELF (round 3; round 2 stored the offset value - base): the sweep packs
+  // without a subtraction per value and checks the range through a running minimum and maximum.  Saves the s=1 sweeps
+  // 2.5 % (47.1 -> 45.9 ms at the headline shape).  At s=2 and 3, where every lane unpacks the ghost row in every step,
+  // it only pays with the two-at-a-time unpacking below (config-4 chunk: offsets 73.4 ms, low halves unpacked value by
+  // value 75, two at a time 72.0).
   // offset of a stored halfword h against the record's base
-  __host__ __device__ static inline uint32_t offset_of(uint32_t h, int base) { return LOWHALF ? (h - (uint32_t)base) & 0xffffu : h; }
+  __host__ __device__ static inline uint32_t offset_of(uint32_t h, int base) { return (h - (uint32_t)base) & 0xffffu; }
+  // ... and of both halfwords of a record dword at once (device code: one v_pk_sub_u16 for two values instead of a
+  // subtraction and a mask each; the caller picks a half, which folds into the addition of the base as an SDWA operand)
+  typedef unsigned short pk_u16x2 __attribute__((ext_vector_type(2)));
+  __device__ static inline uint32_t offsets_of(uint32_t word, int base) {
+    const pk_u16x2 w = __builtin_bit_cast(pk_u16x2, word);
+    const unsigned short b = (unsigned short)base;
+    return __builtin_bit_cast(uint32_t, (pk_u16x2)(w - pk_u16x2{b, b}));
+  }
   // value (state st of band column bb) of a lane slot in a packed record at p
   __host__ __device__ static inline int decode(const int32_t* p, int slot, int bb, int st, bool corner) {
     const int v = bb * 9 + st;
