@@ -135,13 +135,10 @@ def roofline(info, fill_ms, launches, key):
 def self_launch(args, argv):
     """`python bench.py --gpus N` outside torchrun: start the N rank processes as a CHILD (never an exec, and before
     this process has imported torch or touched the GPU), relay rank 0's JSON line and the child's exit code."""
-    import socket
     import subprocess
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    # --standalone: the launcher binds its rendezvous store to a free port itself (no pick-then-bind race)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
+           f"--nproc-per-node={args.gpus}", os.path.abspath(__file__)] + argv
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
     line = None

@@ -16,7 +16,10 @@ def _run(cmd, self_launched=False):
     env = dict(os.environ, BIALIGN_BENCH_REHEARSE="dry")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=280, cwd=REPO)
+    r = subprocess.run(cmd() if callable(cmd) else cmd, env=env, capture_output=True, text=True, timeout=280, cwd=REPO)
+    if callable(cmd) and r.returncode != 0 and any(k in r.stderr for k in ("EADDRINUSE", "ddress already in use", "DistNetworkError")):
+        # the port picked for --master-port was taken between the pick and the launcher's bind: once more, with another
+        r = subprocess.run(cmd(), env=env, capture_output=True, text=True, timeout=280, cwd=REPO)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]  # (gloo prints its connection notes to stdout)
     assert len(lines) == 1, r.stdout
@@ -38,11 +41,13 @@ def test_plain_invocation_starts_its_own_ranks():
 
 
 def test_torchrun_invocation_still_works():
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    _check(_run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                 "--master-addr", "127.0.0.1", "--master-port", str(port), "bench.py", "--gpus", "2"] + ARGS), 2)
+    def cmd():  # the driver's form, on a port that is free right now
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                "--master-addr", "127.0.0.1", "--master-port", str(port), "bench.py", "--gpus", "2"] + ARGS
+    _check(_run(cmd), 2)
 
 
 def test_single_rank_dry():
