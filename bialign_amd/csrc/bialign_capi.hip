@@ -5,6 +5,7 @@
 // stream, time the kernels with HIP events, hand results back.  No CPU compute
 // path exists here: if the device or a kernel is unavailable the call fails.
 #include "bialign_host.hpp"
+#include <cmath>
 
 using namespace bialign;
 
@@ -80,6 +81,9 @@ TeamShape team_shape(const bialign_batch* b, int first, int count, int xcu_resid
   auto concurrent = [&](int t) {
     const size_t lds = (lds_of(t) + 1023) / 1024 * 1024;
     const int wg_cu = (int)std::min<size_t>((160 * 1024) / lds, (size_t)(waves_cu_regs / t));
+    // one workgroup per CU and more workgroups than CUs: they run in rounds, the last one partly empty (300 pairs x len 1024
+    // as eight-wave workgroups: two rounds, 25.2 ms; cross-CU teams of six one-wave workgroups 20.1)
+    if (wg_cu == 1 && count > b->eng->num_cu) return (int64_t)count * t / ((count + b->eng->num_cu - 1) / b->eng->num_cu);
     return std::min<int64_t>((int64_t)count * t, (int64_t)b->eng->num_cu * wg_cu * t);
   };
   // The three-waves-per-SIMD sweep (fill_affine_slim_kernel: 168 registers, no exchange array): teams of 2, 3, 6 or 12
@@ -89,6 +93,16 @@ TeamShape team_shape(const bialign_batch* b, int first, int count, int xcu_resid
     // a workgroup = 12 waves = (12 / t) pairs x teams of t, one per CU: every SIMD holds exactly three waves
     auto conc_slim = [&](int t) { return std::min<int64_t>((int64_t)count * t, (int64_t)b->eng->num_cu * 12); };
     auto fits = [&](int t) { return t <= fit_exact && b->lds_slim(t) <= 160 * 1024; };
+    auto slim_rounds = [&](int t) { return (((int64_t)count * t + 11) / 12 + b->eng->num_cu - 1) / b->eng->num_cu; };
+    auto slim_score = [&](int t) {  // waves at work, averaged over the launch
+      int64_t strips = 0, slots = 0;
+      for (int p = first; p < first + count; ++p) {
+        const int ns = b->pairs[b->order[p]].NS;
+        strips += ns;
+        slots += (int64_t)(ns + t - 1) / t * t;
+      }
+      return (double)count * t / slim_rounds(t) * strips / std::max<int64_t>(slots, 1);
+    };
     static const int sizes[] = {2, 3, 6, 12};  // (a one-wave team spills in hipcc's allocation: 168 registers + scratch)
     int pick = 0;
     if (e) {  // forced in-workgroup team: the slim kernel if it comes in that size
@@ -96,23 +110,43 @@ TeamShape team_shape(const bialign_batch* b, int first, int count, int xcu_resid
       for (int t : sizes)
         if (t == want && fits(t)) pick = t;
     } else {
-      int64_t best_s = 0;
+      // the team that keeps most waves at work over the launch: workgroups beyond one per CU run in rounds (all pairs of a
+      // launch sweep about equally long), and a team of t idles in a pair's last round unless t divides its strips
+      // (2048 pairs x len 512: teams of 2 = 342 workgroups = two rounds, the second a third full, 33.8 ms; teams of 3 =
+      // two full rounds, 25.7 ms.  1280 pairs: teams of 2 in one round 16.5 ms, teams of 3 in two 21.8)
+      double best_s = 0;
       for (int t : sizes)
-        if (fits(t)) best_s = std::max(best_s, conc_slim(t));
+        if (fits(t)) best_s = std::max(best_s, slim_score(t));
       for (int t : sizes)
-        if (!pick && fits(t) && conc_slim(t) * 100 >= best_s * 95) pick = t;
+        if (!pick && fits(t) && slim_score(t) >= best_s * 0.98) pick = t;
     }
-    int64_t best_old = 0;  // what the two-wave kernels' in-workgroup teams keep running at best
-    for (int c = 1; c <= tw; c *= 2) best_old = std::max(best_old, concurrent(c));
+    // what the two-wave kernels' in-workgroup teams keep running at best -- at the two waves per SIMD their registers
+    // really allow (concurrent() counts three, a round-1 calibration of the choice AMONG those kernels)
+    int64_t best_old = 0;
+    for (int c = 1; c <= tw; c *= 2) {
+      const size_t lds = (lds_of(c) + 1023) / 1024 * 1024;
+      const int wg_cu = (int)std::min<size_t>((160 * 1024) / lds, (size_t)std::max(1, 8 / c));
+      best_old = std::max(best_old, std::min<int64_t>((int64_t)count * c, (int64_t)b->eng->num_cu * wg_cu * c));
+    }
     if (pick && !e && conc_slim(pick) < best_old) pick = 0;  // (e.g. 256 pairs whose period admits teams of 6: 1536 waves against 2048)
-    // its twelve-wave workgroups must cover the device: a third wave on a SIMD adds a few percent, an idle CU costs all of
-    // it (117 pairs x len 1024: teams of 12 on 117 CUs 11.0 ms, cross-CU teams of 13 one-wave workgroups on all CUs 9.7)
-    if (pick && !e && ((int64_t)count * pick + 11) / 12 * 10 < (int64_t)b->eng->num_cu * 9) pick = 0;
+    // More pairs than one round of twelve-wave workgroups holds: the two-wave kernel sweeps them with one wave each, every
+    // strip count divides, and workgroups of one wave refill a CU as they finish.  Three slim waves do the work of 2.06
+    // two-wave ones on a SIMD (headline shape: 46.0 against 46.5 ms at strip efficiencies 0.96 and 0.98); a fractional
+    // last round of one-wave workgroups costs about half a round (3072 pairs x len 512: 13.0 ms per 1024 against 11.4 at
+    // 2048).  Measured, ms per 1024 pairs x len 512, slim / two-wave: 2048 pairs 12.8 / 11.4, 3072 11.8 / 13.0, 4096 12.4 / 11.3
+    // (profiles/r03w_exchange/slim_rounds_512.log).
+    if (pick && !e && slim_rounds(pick) > 1) {
+      const double x = std::max(1.0, (double)count / (b->eng->num_cu * 8.0));  // rounds of one-wave workgroups, two per SIMD
+      const double old_score = count / ((std::ceil(x) + x) / 2);
+      if (slim_score(pick) * (2.06 / 3) < old_score) pick = 0;
+    }
     if (pick) {
-      // (a handful of long pairs still go to cross-CU teams of the two-wave kernel below when that spreads them wider)
-      const int64_t run_s = conc_slim(pick);
+      // A handful of long pairs still go to cross-CU teams of the two-wave kernel below when that spreads them wider: a
+      // third wave on a SIMD adds a few percent, an idle CU costs all of it (117 pairs x len 1024: teams of 12 on 117 CUs
+      // 11.0 ms, cross-CU teams of 13 one-wave workgroups on all CUs 9.7).  Three slim waves count as 2.06 two-wave ones.
+      const double run_s = conc_slim(pick) * (2.06 / 3);
       const int g = std::min(gw, std::max(1, 2048 / count));
-      if (e || !(g >= 2 && (int64_t)count * g * 10 >= run_s * 14)) {
+      if (e || !(g >= 2 && (double)count * g >= run_s * 1.4)) {
         ts.tw = pick;
         ts.slim = true;
         return ts;

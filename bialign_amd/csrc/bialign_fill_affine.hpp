@@ -130,7 +130,7 @@ __global__ void __launch_bounds__(64 * TW) BIALIGN_WPE_ATTR fill_affine_kernel(c
   using MF = Mu2Feed<S>;
   constexpr int PERW = GF::RING_DW + NV * NCOL + (DENSE ? MF::RING_DW : 0);  // dwords per wave
   v4i* ring = reinterpret_cast<v4i*>(smem + wl * GF::RING_DW);   // ghost-row ring, two halves
-  int32_t* xch = smem + TW * GF::RING_DW + wl * (NV * NCOL);     // [NV][NCOL] exchange array
+  int32_t* xch = smem + TW * GF::RING_DW + wl * (NV * NCOL);     // exchange array (BIALIGN_XCH_LANE_MAJOR: [NCOL lanes][NV], else [NV][NCOL])
   int32_t* mu2ring = smem + TW * (GF::RING_DW + NV * NCOL) + wl * MF::RING_DW;  // dense-mu2 ring
   volatile int32_t* prog_lds = smem + TW * PERW;                  // [16] (in-workgroup teams)
   int32_t* s1 = smem + TW * PERW + 16;                            // [k1*k1]
@@ -296,10 +296,21 @@ __global__ void __launch_bounds__(64 * TW) BIALIGN_WPE_ATTR fill_affine_kernel(c
   constexpr bool PREF = S <= 1;
   int inA[W][4], inB[W][8];
   auto read_lds = [&](int r) __attribute__((always_inline)) {
+    if (BIALIGN_XCH_LANE_MAJOR) {
+      // a lane's NV values lie together (NV = 12 W dwords: 16-byte aligned, and eight neighbouring lanes' 16-byte pieces
+      // fall into 32 different banks): what a source lane published for band column r comes back as three 16-byte reads
+      const v4i a = *reinterpret_cast<const v4i*>(xch + colLW * NV + r * XR);
+      const v4i b0 = *reinterpret_cast<const v4i*>(xch + colLW1 * NV + r * XR + 4);
+      const v4i b1 = *reinterpret_cast<const v4i*>(xch + colLW1 * NV + r * XR + 8);
+      inA[r][0] = a.x; inA[r][1] = a.y; inA[r][2] = a.z; inA[r][3] = a.w;
+      inB[r][0] = b0.x; inB[r][1] = b0.y; inB[r][2] = b0.z; inB[r][3] = b0.w;
+      inB[r][4] = b1.x; inB[r][5] = b1.y; inB[r][6] = b1.z; inB[r][7] = b1.w;
+    } else {
 #pragma unroll
-    for (int x = 0; x < 4; ++x) inA[r][x] = xch[(r * XR + x) * NCOL + colLW];
+      for (int x = 0; x < 4; ++x) inA[r][x] = xch[(r * XR + x) * NCOL + colLW];
 #pragma unroll
-    for (int x = 0; x < 8; ++x) inB[r][x] = xch[(r * XR + 4 + x) * NCOL + colLW1];
+      for (int x = 0; x < 8; ++x) inB[r][x] = xch[(r * XR + 4 + x) * NCOL + colLW1];
+    }
   };
   // A delay-line stage.  The copy is opaque to the compiler: coalescing it would keep the old value alive in the
   // register the next fetch wants, and the allocator then copies the freshly fetched values at the back-edge instead
@@ -788,17 +799,24 @@ __global__ void __launch_bounds__(64 * TW) BIALIGN_WPE_ATTR fill_affine_kernel(c
         }
       }
       // publish (all reads of this step were issued above, LDS keeps order)
-      int32_t* row = xch + (bb * XR) * NCOL + L;
-      row[0 * NCOL] = Gd[2][2];
-      row[1 * NCOL] = Gd[2][1];
-      row[2 * NCOL] = Gd[1][2];
-      row[3 * NCOL] = Gd[1][1];
-      row[4 * NCOL] = Gd[2][0];
-      row[5 * NCOL] = Gd[1][0];
+      if (BIALIGN_XCH_LANE_MAJOR) {
+        v4i* mine = reinterpret_cast<v4i*>(xch + L * NV + bb * XR);
+        mine[0] = v4i{Gd[2][2], Gd[2][1], Gd[1][2], Gd[1][1]};
+        mine[1] = v4i{Gd[2][0], Gd[1][0], H3[2][0], H3[2][1]};
+        mine[2] = v4i{H3[2][2], H3[1][0], H3[1][1], H3[1][2]};
+      } else {
+        int32_t* row = xch + (bb * XR) * NCOL + L;
+        row[0 * NCOL] = Gd[2][2];
+        row[1 * NCOL] = Gd[2][1];
+        row[2 * NCOL] = Gd[1][2];
+        row[3 * NCOL] = Gd[1][1];
+        row[4 * NCOL] = Gd[2][0];
+        row[5 * NCOL] = Gd[1][0];
 #pragma unroll
-      for (int v = 0; v < 3; ++v) {
-        row[(6 + v) * NCOL] = H3[2][v];
-        row[(9 + v) * NCOL] = H3[1][v];
+        for (int v = 0; v < 3; ++v) {
+          row[(6 + v) * NCOL] = H3[2][v];
+          row[(9 + v) * NCOL] = H3[1][v];
+        }
       }
       pubC[bb][0] = Gd[0][2];
       pubC[bb][1] = Gd[0][1];

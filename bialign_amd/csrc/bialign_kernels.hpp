@@ -57,6 +57,10 @@
 #define BIALIGN_SLIM_DPP 1  // like the rows': 21 VALU less, 21 LDS instructions more per step -- and 4.5 % slower (48.7 vs 46.6 ms)
 #endif
 
+#ifndef BIALIGN_XCH_LANE_MAJOR  // fill_affine_kernel's exchange array: 1 = a lane's 12 W values together (16-byte LDS accesses),
+#define BIALIGN_XCH_LANE_MAJOR 1  // 0 = a row of 65 lane columns per value (4-byte accesses paired by the compiler; rounds 1-3)
+#endif
+
 #ifdef BIALIGN_WPE  // experiment: cap the affine sweep's registers so that this many waves fit a SIMD
 #define BIALIGN_WPE_ATTR __attribute__((amdgpu_waves_per_eu(BIALIGN_WPE, BIALIGN_WPE)))
 #else

@@ -1,4 +1,4 @@
-"""fill time of the s=1 packed affine sweep per (pairs, team, kernel): tools/slim_matrix.py  [AB_LEN=1024]"""
+"""fill time of the s=1 packed affine sweep per (pairs, team, kernel): tools/slim_matrix.py  [AB_LEN=1024] [SLIM_MATRIX=rounds]"""
 import os, sys, subprocess
 length = os.environ.get("AB_LEN", "1024")
 code = r'''
@@ -18,6 +18,8 @@ b.close()
 '''
 cases = [(3072, "1", "1"), (1536, "2", "1"), (1024, "3", "1"), (1024, "6", "1"), (512, "6", "1"), (256, "12", "1"), (2048, "3", "1"),
          (2048, "1", "0"), (1024, "2", "0"), (3072, "1", "0")]
+if os.environ.get("SLIM_MATRIX") == "rounds":  # pair counts beyond one round of twelve-wave workgroups (256 CUs): which team, which kernel
+    cases = [(n, t, sl) for n in (1280, 1536, 2048, 3072, 4096) for t, sl in (("2", "1"), ("3", "1"), ("6", "1"), ("1", "0"), ("2", "0"), ("", "1"))]
 for pairs, team, slim in cases:
     env = dict(os.environ, AB_PAIRS=str(pairs), AB_LEN=length, BIALIGN_TEAM=team, BIALIGN_SLIM=slim)
     subprocess.run([sys.executable, "-c", code], env=env, timeout=300)
