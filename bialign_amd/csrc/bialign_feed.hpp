@@ -30,6 +30,15 @@ struct GhostFeed {
   static constexpr int BLK = BLKO ? BLKO : (S <= 1 ? 8 : 4);  // steps per prefetch block (the ring is 2*BLK*W*NP*16 bytes of LDS)
 #endif
   static constexpr int NPIECE = BLK * W * NP;
+  // Order of the pieces in a ring half.  s <= 1: [step][a][piece] (a lane's record contiguous; the in-place unpacking of the
+  // s=1 sweeps and the slim kernel's dword reads rely on it; 7 pieces = 28 dwords apart, the W = 3 ghost lanes fall into
+  // different banks).  s >= 2: [piece][step][a] -- the W lanes of a ghost row read W neighbouring 16-byte pieces; with the
+  // record contiguous they were NP * 4 dwords apart, 48 at s=2 (a = 0 and a = 4 in the same banks) and 64 at s=3 (all seven in
+  // the same banks: every ghost read of the wave took seven passes).
+  static constexpr bool PIECE_MAJOR = S >= 2;
+  __host__ __device__ static constexpr int slot(int t, int aa, int c) {
+    return PIECE_MAJOR ? (c * BLK + t) * W + aa : (t * W + aa) * NP + c;
+  }
   static constexpr int ROUNDS = (NPIECE + 63) / 64;
   static constexpr int SLOTS = ROUNDS * 64;                  // pieces per ring half (lane-linear)
   static constexpr int RING_DW = 2 * SLOTS * 4;              // two halves, dwords
@@ -46,8 +55,18 @@ struct GhostFeed {
 #pragma unroll
     for (int r = 0; r < ROUNDS; ++r) {
       const int q = min(r * 64 + lane, NPIECE - 1);
-      const int t = q / (W * NP), rem = q - t * (W * NP);
-      const int aa = rem / NP, c = rem - aa * NP;
+      int t, aa, c;
+      if (PIECE_MAJOR) {
+        c = q / (BLK * W);
+        const int rem = q - c * (BLK * W);
+        t = rem / W;
+        aa = rem - t * W;
+      } else {
+        t = q / (W * NP);
+        const int rem = q - t * (W * NP);
+        aa = rem / NP;
+        c = rem - aa * NP;
+      }
       const int xr = blk_rem + t - aa;
       const int ql = blk_q + (xr >= P ? 1 : 0) - (xr < 0 ? 1 : 0);
       const int rec = min(max(h0 + t - GOFF + (ql * (T - 1) + w) * P, 0), rec_last);
@@ -75,8 +94,18 @@ struct GhostFeed {
 #pragma unroll
     for (int r = 0; r < ROUNDS; ++r) {
       const int q = min(r * 64 + lane, NPIECE - 1);
-      const int t = q / (W * NP), rem = q - t * (W * NP);
-      const int aa = rem / NP, c = rem - aa * NP;
+      int t, aa, c;
+      if (PIECE_MAJOR) {
+        c = q / (BLK * W);
+        const int rem = q - c * (BLK * W);
+        t = rem / W;
+        aa = rem - t * W;
+      } else {
+        t = q / (W * NP);
+        const int rem = q - t * (W * NP);
+        aa = rem / NP;
+        c = rem - aa * NP;
+      }
       const int xr = blk_rem + t - aa;
       const int ql = blk_q + (xr >= P ? 1 : 0) - (xr < 0 ? 1 : 0);
       const int jj = xr - (xr >= P ? P : 0) + (xr < 0 ? P : 0);  // the ghost lane's column
@@ -127,19 +156,17 @@ struct GhostFeed {
   // the first NPK pieces only (a packed lane record)
   template <int NPK>
   __device__ static __forceinline__ void fetch_pieces(int (&out)[4 * NPK], const v4i* half, int t, int aa) {
-    const v4i* src = half + (t * W + aa) * NP;
 #pragma unroll
     for (int c = 0; c < NPK; ++c) {
-      const v4i v = src[c];
+      const v4i v = half[slot(t, aa, c)];
       out[4 * c] = v.x; out[4 * c + 1] = v.y; out[4 * c + 2] = v.z; out[4 * c + 3] = v.w;
     }
   }
 
   __device__ static __forceinline__ void fetch(int (&out)[R_::ND], const v4i* half, int t, int aa) {
-    const v4i* src = half + (t * W + aa) * NP;
 #pragma unroll
     for (int c = 0; c < NP; ++c) {
-      const v4i v = src[c];
+      const v4i v = half[slot(t, aa, c)];
       if (4 * c + 0 < R_::ND) out[4 * c + 0 < R_::ND ? 4 * c + 0 : 0] = v.x;
       if (4 * c + 1 < R_::ND) out[4 * c + 1 < R_::ND ? 4 * c + 1 : 0] = v.y;
       if (4 * c + 2 < R_::ND) out[4 * c + 2 < R_::ND ? 4 * c + 2 : 0] = v.z;
