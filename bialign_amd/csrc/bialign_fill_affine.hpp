@@ -130,7 +130,7 @@ __global__ void __launch_bounds__(64 * TW) BIALIGN_WPE_ATTR fill_affine_kernel(c
   using MF = Mu2Feed<S>;
   constexpr int PERW = GF::RING_DW + NV * NCOL + (DENSE ? MF::RING_DW : 0);  // dwords per wave
   v4i* ring = reinterpret_cast<v4i*>(smem + wl * GF::RING_DW);   // ghost-row ring, two halves
-  int32_t* xch = smem + TW * GF::RING_DW + wl * (NV * NCOL);     // exchange array (BIALIGN_XCH_LANE_MAJOR: [NCOL lanes][NV], else [NV][NCOL])
+  int32_t* xch = smem + TW * GF::RING_DW + wl * (NV * NCOL);     // exchange array [NCOL lanes][NV]
   int32_t* mu2ring = smem + TW * (GF::RING_DW + NV * NCOL) + wl * MF::RING_DW;  // dense-mu2 ring
   volatile int32_t* prog_lds = smem + TW * PERW;                  // [16] (in-workgroup teams)
   int32_t* s1 = smem + TW * PERW + 16;                            // [k1*k1]
@@ -296,21 +296,14 @@ __global__ void __launch_bounds__(64 * TW) BIALIGN_WPE_ATTR fill_affine_kernel(c
   constexpr bool PREF = S <= 1;
   int inA[W][4], inB[W][8];
   auto read_lds = [&](int r) __attribute__((always_inline)) {
-    if (BIALIGN_XCH_LANE_MAJOR) {
-      // a lane's NV values lie together (NV = 12 W dwords: 16-byte aligned, and eight neighbouring lanes' 16-byte pieces
-      // fall into 32 different banks): what a source lane published for band column r comes back as three 16-byte reads
-      const v4i a = *reinterpret_cast<const v4i*>(xch + colLW * NV + r * XR);
-      const v4i b0 = *reinterpret_cast<const v4i*>(xch + colLW1 * NV + r * XR + 4);
-      const v4i b1 = *reinterpret_cast<const v4i*>(xch + colLW1 * NV + r * XR + 8);
-      inA[r][0] = a.x; inA[r][1] = a.y; inA[r][2] = a.z; inA[r][3] = a.w;
-      inB[r][0] = b0.x; inB[r][1] = b0.y; inB[r][2] = b0.z; inB[r][3] = b0.w;
-      inB[r][4] = b1.x; inB[r][5] = b1.y; inB[r][6] = b1.z; inB[r][7] = b1.w;
-    } else {
-#pragma unroll
-      for (int x = 0; x < 4; ++x) inA[r][x] = xch[(r * XR + x) * NCOL + colLW];
-#pragma unroll
-      for (int x = 0; x < 8; ++x) inB[r][x] = xch[(r * XR + 4 + x) * NCOL + colLW1];
-    }
+    // a lane's NV values lie together (NV = 12 W dwords: 16-byte aligned, and eight neighbouring lanes' 16-byte pieces
+    // fall into 32 different banks): what a source lane published for band column r comes back as three 16-byte reads
+    const v4i a = *reinterpret_cast<const v4i*>(xch + colLW * NV + r * XR);
+    const v4i b0 = *reinterpret_cast<const v4i*>(xch + colLW1 * NV + r * XR + 4);
+    const v4i b1 = *reinterpret_cast<const v4i*>(xch + colLW1 * NV + r * XR + 8);
+    inA[r][0] = a.x; inA[r][1] = a.y; inA[r][2] = a.z; inA[r][3] = a.w;
+    inB[r][0] = b0.x; inB[r][1] = b0.y; inB[r][2] = b0.z; inB[r][3] = b0.w;
+    inB[r][4] = b1.x; inB[r][5] = b1.y; inB[r][6] = b1.z; inB[r][7] = b1.w;
   };
   // A delay-line stage.  The copy is opaque to the compiler: coalescing it would keep the old value alive in the
   // register the next fetch wants, and the allocator then copies the freshly fetched values at the back-edge instead
@@ -456,38 +449,30 @@ __global__ void __launch_bounds__(64 * TW) BIALIGN_WPE_ATTR fill_affine_kernel(c
       // step old" broke the dense s=2,3 kernels in round 3); lane 0 reads out of range -> 0
       // with bound_ctrl, it is an a_first lane anyway.  H2[.][M] (x = 2..4) of the last band column has
       // no consumer: offset (0,0,M) from there would leave the band.
-      if (BIALIGN_OPT & 1) {
-        if (r + 1 < W) {
-          asm("s_nop 1\n\t"
-              "v_min_i32_dpp %0, %8, %16 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-              "v_min_i32_dpp %1, %9, %16 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-              "v_min_i32_dpp %2, %10, %16 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-              "v_min_i32_dpp %3, %11, %16 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-              "v_min_i32_dpp %4, %12, %16 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-              "v_min_i32_dpp %5, %13, %16 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-              "v_min_i32_dpp %6, %14, %16 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-              "v_min_i32_dpp %7, %15, %16 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1"
-              : "=&v"(inC[r][0]), "=&v"(inC[r][1]), "=&v"(inC[r][2]), "=&v"(inC[r][3]), "=&v"(inC[r][4]),
-                "=&v"(inC[r][5]), "=&v"(inC[r][6]), "=&v"(inC[r][7])
-              : "v"(pubC[r][0]), "v"(pubC[r][1]), "v"(pubC[r][2]), "v"(pubC[r][3]), "v"(pubC[r][4]),
-                "v"(pubC[r][5]), "v"(pubC[r][6]), "v"(pubC[r][7]), "v"(lane_cap));
-        } else {
-          asm("s_nop 1\n\t"
-              "v_min_i32_dpp %0, %5, %10 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-              "v_min_i32_dpp %1, %6, %10 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-              "v_min_i32_dpp %2, %7, %10 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-              "v_min_i32_dpp %3, %8, %10 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-              "v_min_i32_dpp %4, %9, %10 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1"
-              : "=&v"(inC[r][0]), "=&v"(inC[r][1]), "=&v"(inC[r][5]), "=&v"(inC[r][6]), "=&v"(inC[r][7])
-              : "v"(pubC[r][0]), "v"(pubC[r][1]), "v"(pubC[r][5]), "v"(pubC[r][6]), "v"(pubC[r][7]), "v"(lane_cap));
-          inC[r][2] = inC[r][3] = inC[r][4] = SENT;
-        }
+      if (r + 1 < W) {
+        asm("s_nop 1\n\t"
+            "v_min_i32_dpp %0, %8, %16 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+            "v_min_i32_dpp %1, %9, %16 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+            "v_min_i32_dpp %2, %10, %16 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+            "v_min_i32_dpp %3, %11, %16 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+            "v_min_i32_dpp %4, %12, %16 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+            "v_min_i32_dpp %5, %13, %16 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+            "v_min_i32_dpp %6, %14, %16 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+            "v_min_i32_dpp %7, %15, %16 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+            : "=&v"(inC[r][0]), "=&v"(inC[r][1]), "=&v"(inC[r][2]), "=&v"(inC[r][3]), "=&v"(inC[r][4]),
+              "=&v"(inC[r][5]), "=&v"(inC[r][6]), "=&v"(inC[r][7])
+            : "v"(pubC[r][0]), "v"(pubC[r][1]), "v"(pubC[r][2]), "v"(pubC[r][3]), "v"(pubC[r][4]),
+              "v"(pubC[r][5]), "v"(pubC[r][6]), "v"(pubC[r][7]), "v"(lane_cap));
       } else {
-#pragma unroll
-        for (int x = 0; x < 8; ++x) {
-          const int nb = __builtin_amdgcn_mov_dpp(pubC[r][x], 0x138 /* wave_shr:1 */, 0xf, 0xf, true);
-          inC[r][x] = a_first ? SENT : nb;
-        }
+        asm("s_nop 1\n\t"
+            "v_min_i32_dpp %0, %5, %10 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+            "v_min_i32_dpp %1, %6, %10 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+            "v_min_i32_dpp %2, %7, %10 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+            "v_min_i32_dpp %3, %8, %10 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+            "v_min_i32_dpp %4, %9, %10 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+            : "=&v"(inC[r][0]), "=&v"(inC[r][1]), "=&v"(inC[r][5]), "=&v"(inC[r][6]), "=&v"(inC[r][7])
+            : "v"(pubC[r][0]), "v"(pubC[r][1]), "v"(pubC[r][5]), "v"(pubC[r][6]), "v"(pubC[r][7]), "v"(lane_cap));
+        inC[r][2] = inC[r][3] = inC[r][4] = SENT;
       }
     };
     read_rows(0);
@@ -591,7 +576,7 @@ __global__ void __launch_bounds__(64 * TW) BIALIGN_WPE_ATTR fill_affine_kernel(c
 
           int t = SENT;
           bool any = false;
-          if (BIALIGN_OPT2 && hU < 2 && hV < 2 && ok2 && ok3) {
+          if (hU < 2 && hV < 2 && ok2 && ok3) {
             // both gap-gap groups cost gamma + Delta: max(c1 + g, gD + h2, gD + h3) = gD + max(g + (c1 - gD), h2, h3),
             // exact in integers, one add less (c1 - gD is wave-uniform: gamma - Delta or gamma + Delta)
             const int inner = ok1 ? imax(imax(gin + (c1 - gD), h2in), h3in) : imax(h2in, h3in);
@@ -610,7 +595,7 @@ __global__ void __launch_bounds__(64 * TW) BIALIGN_WPE_ATTR fill_affine_kernel(c
       // (pyx:299-303); points outside the lattice carry the sentinel.
       int M[9];
       bool isneg[9] = {};  // "no valid case" per corner state, as the finalisation found it (computing lanes)
-      if (INTERIOR && (BIALIGN_OPT & 2)) {
+      if (INTERIOR) {
         // ghost lanes keep what the ring delivered; the others compute in place under the
         // execution mask (no per-value select)
 #pragma unroll
@@ -627,15 +612,6 @@ __global__ void __launch_bounds__(64 * TW) BIALIGN_WPE_ATTR fill_affine_kernel(c
             }
             M[q] = tv;
           }
-        }
-      } else if (INTERIOR) {
-        int Tv[9];
-        cases(Tv);
-#pragma unroll
-        for (int q = 0; q < 9; ++q) {
-          int tv = ghost ? ghostM[bb * 9 + q] : Tv[q];
-          if (can_be_empty<W>(q / 3, q % 3, bb)) tv = tv < THRESH ? NEG : tv;
-          M[q] = tv;
         }
       } else {
         int Tv[9];
@@ -677,7 +653,7 @@ __global__ void __launch_bounds__(64 * TW) BIALIGN_WPE_ATTR fill_affine_kernel(c
             if (pack_corner(W, q, bb)) {  // offset 0xffff is the -2^30 mark here: base + 0xffff stands in for the value, in the
               // record and in the running minimum alike (it is the largest value a record can hold; a finite value that
               // happens to equal -2^30 is not marked and fails the range check)
-              const bool ng = (BIALIGN_OPT2 != 0 && (BIALIGN_OPT & 2) != 0) ? isneg[q] : M[q] == NEG;
+              const bool ng = isneg[q];
               x = ng ? pk_base + 0xffff : x;
             }
             pk_e[PACK ? bb * 9 + q : 0] = x;  // (the record takes the low half)
@@ -693,11 +669,9 @@ __global__ void __launch_bounds__(64 * TW) BIALIGN_WPE_ATTR fill_affine_kernel(c
 #pragma unroll
           for (int c = 0; c < PK_::NPC; ++c) {
             constexpr int NDWc = PK_::NDW;
-            const int dlast = 4 * c + 3 < NDWc - 1 ? 4 * c + 3 : NDWc - 1;  // last lane-record dword of piece c
-            const int last = PK_::val(2 * dlast + 1);                        // ... and the last value it holds
             // (issued together after the last point: the packed sweep is bound by issue, not by the store queue -- spreading
             //  them over the step, which paid 6 % with full records, now costs 1-2.5 %: config-4 chunk 78.5 vs 76.5 ms)
-            if ((BIALIGN_OPT & 4) ? bb == W - 1 : (last >= bb * 9 && last < (bb + 1) * 9)) {
+            if (bb == W - 1) {
               int dw[4];
 #pragma unroll
               for (int x = 0; x < 4; ++x) {
@@ -799,25 +773,10 @@ __global__ void __launch_bounds__(64 * TW) BIALIGN_WPE_ATTR fill_affine_kernel(c
         }
       }
       // publish (all reads of this step were issued above, LDS keeps order)
-      if (BIALIGN_XCH_LANE_MAJOR) {
-        v4i* mine = reinterpret_cast<v4i*>(xch + L * NV + bb * XR);
-        mine[0] = v4i{Gd[2][2], Gd[2][1], Gd[1][2], Gd[1][1]};
-        mine[1] = v4i{Gd[2][0], Gd[1][0], H3[2][0], H3[2][1]};
-        mine[2] = v4i{H3[2][2], H3[1][0], H3[1][1], H3[1][2]};
-      } else {
-        int32_t* row = xch + (bb * XR) * NCOL + L;
-        row[0 * NCOL] = Gd[2][2];
-        row[1 * NCOL] = Gd[2][1];
-        row[2 * NCOL] = Gd[1][2];
-        row[3 * NCOL] = Gd[1][1];
-        row[4 * NCOL] = Gd[2][0];
-        row[5 * NCOL] = Gd[1][0];
-#pragma unroll
-        for (int v = 0; v < 3; ++v) {
-          row[(6 + v) * NCOL] = H3[2][v];
-          row[(9 + v) * NCOL] = H3[1][v];
-        }
-      }
+      v4i* mine = reinterpret_cast<v4i*>(xch + L * NV + bb * XR);
+      mine[0] = v4i{Gd[2][2], Gd[2][1], Gd[1][2], Gd[1][1]};
+      mine[1] = v4i{Gd[2][0], Gd[1][0], H3[2][0], H3[2][1]};
+      mine[2] = v4i{H3[2][2], H3[1][0], H3[1][1], H3[1][2]};
       pubC[bb][0] = Gd[0][2];
       pubC[bb][1] = Gd[0][1];
 #pragma unroll

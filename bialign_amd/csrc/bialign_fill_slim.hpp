@@ -376,7 +376,7 @@ __global__ void __launch_bounds__(64 * TW * PPW, 3) fill_affine_slim_kernel(cons
             const int c3 = (hU == 2) ? c3M : gD;
             int t = SENT;
             bool any = false;
-            if (BIALIGN_OPT2 && hU < 2 && hV < 2 && ok2 && ok3) {
+            if (hU < 2 && hV < 2 && ok2 && ok3) {
               // both gap-gap groups cost gamma + Delta: max(c1 + g, gD + h2, gD + h3) = gD + max(g + (c1 - gD), h2, h3),
               // exact in integers, one add less (c1 - gD is wave-uniform: gamma - Delta or gamma + Delta)
               const int inner = ok1 ? imax(imax(gin + (c1 - gD), h2in), h3in) : imax(h2in, h3in);
@@ -459,7 +459,7 @@ __global__ void __launch_bounds__(64 * TW * PPW, 3) fill_affine_slim_kernel(cons
             if (pack_corner(W, q, bb)) {  // offset 0xffff is the -2^30 mark here: base + 0xffff stands in for the value, in the
               // record and in the running minimum alike (it is the largest value a record can hold; a finite value that
               // happens to equal -2^30 is not marked and fails the range check)
-              const bool ng = BIALIGN_OPT2 ? isneg[q] : M[q] == NEG;
+              const bool ng = isneg[q];
               x = ng ? pk_base + 0xffff : x;
             }
             pk_e[PACKED ? bb * 9 + q : 0] = x;  // (the record takes the low half)

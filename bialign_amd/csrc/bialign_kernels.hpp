@@ -45,20 +45,8 @@
 #ifndef BIALIGN_PADMAX
 #define BIALIGN_PADMAX 2
 #endif
-#ifndef BIALIGN_OPT  // A/B switches of equivalent step code: 1 = fused DPP-min exchange, 2 = ghost rows by branch,
-#define BIALIGN_OPT 7  // 4 = packed records: all of a step's stores after its last point (one exec region instead of NCH)
-#endif
-
-#ifndef BIALIGN_OPT2  // round 3 instruction diet of the affine step (0: off, for A/B): gap-gap groups share their add; the
-#define BIALIGN_OPT2 1  // packer reuses the finalisation's "no valid case" test
-#endif
-
 #ifndef BIALIGN_SLIM_DPP  // fill_affine_slim_kernel: 1 = lane L-1's values by DPP (as fill_affine_kernel), 0 = by ds_bpermute
 #define BIALIGN_SLIM_DPP 1  // like the rows': 21 VALU less, 21 LDS instructions more per step -- and 4.5 % slower (48.7 vs 46.6 ms)
-#endif
-
-#ifndef BIALIGN_XCH_LANE_MAJOR  // fill_affine_kernel's exchange array: 1 = a lane's 12 W values together (16-byte LDS accesses),
-#define BIALIGN_XCH_LANE_MAJOR 1  // 0 = a row of 65 lane columns per value (4-byte accesses paired by the compiler; rounds 1-3)
 #endif
 
 #ifdef BIALIGN_WPE  // experiment: cap the affine sweep's registers so that this many waves fit a SIMD
