@@ -176,7 +176,10 @@ TeamShape team_shape(const bialign_batch* b, int first, int count, int xcu_resid
   int64_t running = concurrent(t);
   {
     const int g = std::min(gw, std::max(1, 2048 / count));
-    if (g >= 2 && ((int64_t)count * g * 10 >= running * 14 || (t == 8 && g >= 8 && count * 8 <= b->eng->num_cu))) {
+    // (s=1 affine, the in-workgroup shape leaving a third of the wave slots empty: 1.2 x is enough -- 300 pairs x len 1024 as
+    //  teams of 4 in one workgroup 23.3 ms, as eight-wave workgroups in two rounds 25.2, as cross-CU teams of 5 19.9)
+    const bool sparse_s1 = b->affine && b->S == 1 && !b->dense && running * 100 < 2048 * 65;
+    if (g >= 2 && ((int64_t)count * g * 10 >= running * (sparse_s1 ? 12 : 14) || (t == 8 && g >= 8 && count * 8 <= b->eng->num_cu))) {
       ts.tw = 1;
       ts.gw = g;
       running = (int64_t)count * g;
